@@ -1,0 +1,206 @@
+"""ctypes binding of oracle/liboracle.so — the CPU restatement of the reference.
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the cpu_baseline
+leg of bench.py. The product (raytracing_amd/) never imports this.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+orc_hit_dtype = np.dtype([("hit", "<i4"), ("sphere_id", "<i4"), ("material_id", "<i4"), ("front_face", "<i4"),
+                          ("t", "<f8"), ("point", "<f8", 3), ("normal", "<f8", 3), ("margin", "<f8")])
+orc_scatter_dtype = np.dtype([("scattered", "<i4"), ("pad", "<i4"), ("albedo", "<f8", 3), ("origin", "<f8", 3),
+                              ("dir", "<f8", 3), ("time", "<f8")])
+orc_ray_dtype = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3), ("time", "<f8")])
+
+MODE_COUNTER, MODE_REFERENCE = 0, 1
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise FileNotFoundError(f"{LIB_PATH} missing: run `make -C oracle`")
+        lib = C.CDLL(LIB_PATH)
+        vp = C.c_void_p
+        d3 = C.POINTER(C.c_double)
+        lib.orc_vec3_norm.restype = C.c_double
+        lib.orc_vec3_norm.argtypes = [d3]
+        lib.orc_vec3_normalized.argtypes = [d3, d3]
+        lib.orc_vec3_checked_normalized.argtypes = [d3, d3]
+        lib.orc_vec3_map_floor_times2.argtypes = [d3, d3]
+        lib.orc_vec3_dot.restype = C.c_double
+        lib.orc_vec3_dot.argtypes = [d3, d3]
+        lib.orc_vec3_cross.argtypes = [d3, d3, d3]
+        lib.orc_vec3_reflect.argtypes = [d3, d3, d3]
+        lib.orc_vec3_refract.argtypes = [d3, d3, C.c_double, d3]
+        for f in ("orc_lerp",):
+            getattr(lib, f).restype = C.c_double
+            getattr(lib, f).argtypes = [C.c_double] * 3
+        lib.orc_smooth.restype = C.c_double
+        lib.orc_smooth.argtypes = [C.c_double]
+        lib.orc_schlick.restype = C.c_double
+        lib.orc_schlick.argtypes = [C.c_double, C.c_double]
+        lib.orc_philox.argtypes = [C.c_uint64, vp, C.c_uint32, vp]
+        lib.orc_pcg64mcg.argtypes = [C.c_uint64, C.c_uint32, vp]
+        lib.orc_map_unit_sphere.argtypes = [C.c_double, C.c_double, d3]
+        lib.orc_map_unit_disk.argtypes = [C.c_double, C.c_double, d3]
+        lib.orc_pcg_unit_sphere.argtypes = [C.c_uint64, C.c_uint32, vp]
+        lib.orc_pcg_unit_disk.argtypes = [C.c_uint64, C.c_uint32, vp]
+        lib.orc_intersect_batch.argtypes = [vp, vp, C.c_uint32, C.c_double, C.c_int, C.c_uint64, C.c_int, vp]
+        lib.orc_scatter_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, vp]
+        lib.orc_texture_batch.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp]
+        lib.orc_camera_rays.argtypes = [vp, vp, vp, C.c_uint32, vp]
+        lib.orc_render.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int, C.c_uint32,
+                                   C.c_uint32, vp, C.POINTER(C.c_double), C.POINTER(C.c_uint64)]
+        lib.orc_encode.restype = C.c_uint32
+        lib.orc_encode.argtypes = [vp, C.c_uint64, vp]
+        lib.orc_bvh_stats.argtypes = [vp, C.c_int, C.c_uint64, C.POINTER(C.c_int)]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def _d3(v):
+    return (C.c_double * 3)(*[float(x) for x in v])
+
+
+def vec3_norm(v):
+    return load().orc_vec3_norm(_d3(v))
+
+
+def vec3_normalized(v):
+    o = (C.c_double * 3)()
+    load().orc_vec3_normalized(_d3(v), o)
+    return np.array(o[:])
+
+
+def vec3_checked_normalized(v):
+    o = (C.c_double * 3)()
+    rc = load().orc_vec3_checked_normalized(_d3(v), o)
+    return rc, np.array(o[:])
+
+
+def vec3_map_floor_times2(v):
+    o = (C.c_double * 3)()
+    load().orc_vec3_map_floor_times2(_d3(v), o)
+    return np.array(o[:])
+
+
+def vec3_dot(a, b):
+    return load().orc_vec3_dot(_d3(a), _d3(b))
+
+
+def vec3_cross(a, b):
+    o = (C.c_double * 3)()
+    load().orc_vec3_cross(_d3(a), _d3(b), o)
+    return np.array(o[:])
+
+
+def vec3_reflect(d, n):
+    o = (C.c_double * 3)()
+    load().orc_vec3_reflect(_d3(d), _d3(n), o)
+    return np.array(o[:])
+
+
+def vec3_refract(d, n, eta):
+    o = (C.c_double * 3)()
+    load().orc_vec3_refract(_d3(d), _d3(n), float(eta), o)
+    return np.array(o[:])
+
+
+def philox(seed: int, counters4: np.ndarray) -> np.ndarray:
+    c = np.ascontiguousarray(counters4, dtype=np.uint32).reshape(-1, 4)
+    out = np.zeros_like(c)
+    load().orc_philox(seed, _p(c), c.shape[0], _p(out))
+    return out
+
+
+def pcg64mcg(seed: int, n: int) -> np.ndarray:
+    out = np.zeros(n, np.uint64)
+    load().orc_pcg64mcg(seed, n, _p(out))
+    return out
+
+
+def map_unit_sphere(u0, u1):
+    o = (C.c_double * 3)()
+    load().orc_map_unit_sphere(u0, u1, o)
+    return np.array(o[:])
+
+
+def map_unit_disk(u0, u1):
+    o = (C.c_double * 3)()
+    load().orc_map_unit_disk(u0, u1, o)
+    return np.array(o[:])
+
+
+def pcg_unit_sphere(seed, n):
+    out = np.zeros((n, 3))
+    load().orc_pcg_unit_sphere(seed, n, _p(out))
+    return out
+
+
+def pcg_unit_disk(seed, n):
+    out = np.zeros((n, 3))
+    load().orc_pcg_unit_disk(seed, n, _p(out))
+    return out
+
+
+def intersect_batch(scene, rays, t_min=1e-3, bvh_first=-1, bvh_seed=0, precision=64):
+    """scene: ctypes rt_scene struct (raytracing_amd.api.Scene); rays: rt_ray numpy array."""
+    out = np.zeros(rays.shape[0], orc_hit_dtype)
+    load().orc_intersect_batch(C.addressof(scene), _p(rays), rays.shape[0], t_min, bvh_first, bvh_seed, precision,
+                               _p(out))
+    return out
+
+
+def scatter_batch(scene, rays, hits_f32, randoms4):
+    u = np.ascontiguousarray(randoms4, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros(rays.shape[0], orc_scatter_dtype)
+    load().orc_scatter_batch(C.addressof(scene), _p(rays), _p(hits_f32), _p(u), rays.shape[0], _p(out))
+    return out
+
+
+def texture_batch(scene, tex_id, points):
+    p = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 3)
+    out = np.zeros(p.shape, np.float64)
+    rc = load().orc_texture_batch(C.addressof(scene), tex_id, _p(p), p.shape[0], _p(out))
+    assert rc == 0
+    return out
+
+
+def camera_rays(cam, ij, randoms4):
+    ij = np.ascontiguousarray(ij, dtype=np.float32).reshape(-1, 2)
+    u = np.ascontiguousarray(randoms4, dtype=np.float32).reshape(-1, 4)
+    out = np.zeros(ij.shape[0], orc_ray_dtype)
+    load().orc_camera_rays(C.addressof(cam), _p(ij), _p(u), ij.shape[0], _p(out))
+    return out
+
+
+def render(scene, cam, params, mode=MODE_COUNTER, bvh_first=-1, bvh_seed=0, n_threads=1, precision=64,
+           y_begin=0, y_end=0xFFFFFFFF):
+    """Returns (H, W, 3) float64 means (rows outside [y_begin, y_end) are zero), seconds, rays."""
+    out = np.zeros((params.height, params.width, 3), np.float64)
+    sec = C.c_double(0)
+    rays = C.c_uint64(0)
+    load().orc_render(C.addressof(scene), C.addressof(cam), C.addressof(params), mode, bvh_first, bvh_seed,
+                      n_threads, precision, y_begin, y_end, _p(out), C.byref(sec), C.byref(rays))
+    return out, sec.value, int(rays.value)
+
+
+def encode(rgb):
+    a = np.ascontiguousarray(rgb, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros(a.shape[0], np.uint32)
+    bad = load().orc_encode(_p(a), a.shape[0], _p(out))
+    return out, int(bad)

@@ -1,0 +1,479 @@
+// rt_device.h — gfx950 device code of the path-tracing hot path (included by rt_lib.hip only).
+//
+// Written for CDNA4 directly: 64-wide wavefronts, the sphere list broadcast out of LDS with
+// ds_read_b128 (all lanes one address: conflict-free), fp32 VALU for the N-sphere scan, f64 VALU
+// for the one winning sphere per bounce, no MFMA (nothing here is a dense contraction).
+//
+// Reference behaviour restated (file:line in /root/reference/src):
+//   closest hit     hit.rs:100-110 (HitList::hit), shape.rs:35-65, :101-133 (sphere quadratics)
+//   hit record      hit.rs:45-61 (front_face / normal flip)
+//   materials       material.rs:36-41 (Lambertian), :61-72 (Metal), :91-111 (Dielectric), :84-88 (schlick)
+//   vector helpers  vec3.rs:113-123 (reflect normalises first; refract)
+//   textures        color.rs:31-35, material.rs:155-165 (checker), :322-361 (value noise),
+//                   :427-521 (Perlin), :184-263 (fBm / turbulence / marbled)
+//   camera          screen.rs:79-94
+//   integrator      main.rs:110-139, pixel/sample loop main.rs:75-89
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtx_hip.h"
+
+namespace rtd {
+
+constexpr int kChunk = 8;           // spheres per scan chunk (winner id is recovered per chunk)
+constexpr uint32_t kInfBits = 0x7F800000u;
+constexpr float kTwoPow32 = 4294967296.0f;
+
+struct DevTexture {
+    rt_texture t;
+    float fractal_max;  // (1 - gain^layers) / (1 - gain), material.rs:189,216 (computed in f64 on upload)
+    int32_t pad[3];
+};
+
+// Device view of an uploaded scene.
+struct DevScene {
+    // fp32 scan lists (global copies; each workgroup stages them into LDS)
+    const float4* stat;   // ns_pad x {cx, cy, cz, r^2}; pads have r^2 = -1 (never hit)
+    const float4* mov_a;  // nm_pad x {c0x, c0y, c0z, r^2}
+    const float4* mov_b;  // nm_pad x {dcx, dcy, dcz, 0}
+    const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
+    int32_t ns_pad, nm_pad;
+    // spheres too large for the fp32 scan (|c|,r >> 1: e.g. the r = 1000 ground): f64 test
+    const int32_t* big_id;
+    int32_t n_big;
+    // world-order SoA for the f64 hit record of the winning sphere
+    const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad;
+    const uint32_t* mat_id;
+    const rt_material* mats;
+    const DevTexture* texs;
+    const rt_noise_table* tables;
+    int32_t n_tables;
+    int32_t n_spheres;
+    int32_t n_textures;
+};
+
+// LDS image of the scene: [stat | mov_a | mov_b | tables]
+struct LdsScene {
+    const float4* stat;
+    const float4* mov_a;
+    const float4* mov_b;
+    const rt_noise_table* tables;
+};
+
+__host__ __device__ inline size_t lds_scene_bytes(int ns_pad, int nm_pad, int n_tables) {
+    return (size_t)ns_pad * 16 + (size_t)nm_pad * 32 + (size_t)n_tables * sizeof(rt_noise_table);
+}
+
+__device__ inline LdsScene stage_scene(const DevScene& S, unsigned char* lds, int tid, int nthreads) {
+    float4* stat = reinterpret_cast<float4*>(lds);
+    float4* mov_a = stat + S.ns_pad;
+    float4* mov_b = mov_a + S.nm_pad;
+    uint4* tab = reinterpret_cast<uint4*>(mov_b + S.nm_pad);
+    for (int i = tid; i < S.ns_pad; i += nthreads) stat[i] = S.stat[i];
+    for (int i = tid; i < S.nm_pad; i += nthreads) { mov_a[i] = S.mov_a[i]; mov_b[i] = S.mov_b[i]; }
+    const uint4* gt = reinterpret_cast<const uint4*>(S.tables);
+    const int nt = S.n_tables * (int)(sizeof(rt_noise_table) / 16);
+    for (int i = tid; i < nt; i += nthreads) tab[i] = gt[i];
+    __syncthreads();
+    return {stat, mov_a, mov_b, reinterpret_cast<const rt_noise_table*>(tab)};
+}
+
+// ------------------------------------------------------------------ counter RNG
+// Philox4x32-10 (Salmon et al. 2011).  Independent of the oracle's copy; tests compare the two
+// bit for bit and against the Random123 known-answer vectors.
+__device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
+                                              uint32_t c3, uint32_t out[4]) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+// counter = (pixel, sample, dim, 0); dims as in oracle/rt_oracle.hpp
+enum { DIM_PIXEL = 0, DIM_TIME = 1, DIM_BOUNCE0 = 2 };
+
+// ------------------------------------------------------------------ small vector helpers
+struct f3 {
+    float x, y, z;
+};
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ f3 normalize(f3 a) {
+    const float n = sqrtf(dot(a, a));
+    return {a.x / n, a.y / n, a.z / n};
+}
+
+struct Ray {
+    f3 o, d;
+    float time;
+};
+struct HitRec {
+    int32_t sphere;  // -1 = miss
+    int32_t front;
+    float t;
+    f3 p, n;
+};
+
+// uniform on the unit sphere surface / in the unit disc from two uniforms (same maps as the
+// oracle; same distributions as rand_distr::UnitSphere / UnitDisc used at vec3.rs:53-62)
+__device__ __forceinline__ f3 map_unit_sphere(float u0, float u1) {
+    const float z = 1.0f - 2.0f * u0;
+    const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    float s, c;
+    sincospif(2.0f * u1, &s, &c);
+    return {r * c, r * s, z};
+}
+__device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
+    const float r = sqrtf(u0);
+    float s, c;
+    sincospif(2.0f * u1, &s, &c);
+    return {r * c, r * s, 0.0f};
+}
+
+// ------------------------------------------------------------------ the fp32 sphere scan
+// One sphere against one ray, in a frame where the ray starts at o' = o + t_min*d and has a
+// UNIT direction.  Returns the bits of t' = (t - t_min)*|d| for the root the reference would
+// take, or a pattern that loses every unsigned min (negative -> sign bit set, miss -> NaN):
+//   nq = r^2 - |c - o'|^2  (> 0: o' inside the sphere)     b = (c - o').d      disc = b^2 + nq
+//   roots t' = b -+ sqrt(disc); their product is -nq, so exactly one root is positive when
+//   o' is inside (take b + s) and both have the sign of b when outside (take b - s): this is
+//   shape.rs:53-61's "near root if in range else far root" with the range start folded into o'.
+// 10 FMA-class ops + v_sqrt + v_bfi + v_add per sphere; the scan keeps only min(t') (v_min3_u32
+// takes two spheres per instruction) and, per chunk of 8, which chunk last lowered it.
+__device__ __forceinline__ uint32_t sphere_key(float cx, float cy, float cz, float r2, float ox, float oy,
+                                               float oz, float dx, float dy, float dz) {
+    const float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+    const float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+    const float nq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, r2)));
+    const float disc = fmaf(b, b, nq);
+    const float s = __builtin_amdgcn_sqrtf(disc);  // raw v_sqrt_f32: NaN for disc < 0
+    const float t = b + __builtin_copysignf(s, nq);
+    return __float_as_uint(t);
+}
+
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
+
+// Scan both LDS lists.  `best` enters as the bound from the big-sphere test (or +inf bits).
+// On return `slot` is the chunk base (static: [0, ns_pad), moving: ns_pad + [0, nm_pad)) of the
+// chunk that produced the final minimum, or -1 when no small sphere beat the incoming bound.
+__device__ __forceinline__ void scan_spheres(const LdsScene& L, int ns_pad, int nm_pad, float ox, float oy,
+                                             float oz, float dx, float dy, float dz, float time,
+                                             uint32_t& best, int& slot) {
+    for (int base = 0; base < ns_pad; base += kChunk) {
+        const uint32_t prev = best;
+#pragma unroll
+        for (int k = 0; k < kChunk; k += 2) {
+            const float4 a = L.stat[base + k], c = L.stat[base + k + 1];
+            const uint32_t ka = sphere_key(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
+            const uint32_t kc = sphere_key(c.x, c.y, c.z, c.w, ox, oy, oz, dx, dy, dz);
+            best = umin3(best, ka, kc);
+        }
+        slot = (best != prev) ? base : slot;
+    }
+    for (int base = 0; base < nm_pad; base += kChunk) {
+        const uint32_t prev = best;
+#pragma unroll
+        for (int k = 0; k < kChunk; k += 2) {
+            const float4 a = L.mov_a[base + k], ad = L.mov_b[base + k];
+            const float4 c = L.mov_a[base + k + 1], cd = L.mov_b[base + k + 1];
+            // center(time) = c0 + time*dc (shape.rs:96-98)
+            const uint32_t ka = sphere_key(fmaf(time, ad.x, a.x), fmaf(time, ad.y, a.y), fmaf(time, ad.z, a.z),
+                                           a.w, ox, oy, oz, dx, dy, dz);
+            const uint32_t kc = sphere_key(fmaf(time, cd.x, c.x), fmaf(time, cd.y, c.y), fmaf(time, cd.z, c.z),
+                                           c.w, ox, oy, oz, dx, dy, dz);
+            best = umin3(best, ka, kc);
+        }
+        slot = (best != prev) ? ns_pad + base : slot;
+    }
+}
+
+// Which of the 8 spheres of chunk `slot` is the closest: per-lane LDS gather, once per bounce.
+__device__ __forceinline__ int resolve_slot(const LdsScene& L, int ns_pad, int slot, float ox, float oy, float oz,
+                                            float dx, float dy, float dz, float time) {
+    uint32_t best = 0xFFFFFFFFu;
+    int idx = slot;
+    if (slot < ns_pad) {
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            const float4 a = L.stat[slot + k];
+            const uint32_t key = sphere_key(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
+            if (key < best) { best = key; idx = slot + k; }
+        }
+    } else {
+        const int m = slot - ns_pad;
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            const float4 a = L.mov_a[m + k], ad = L.mov_b[m + k];
+            const uint32_t key = sphere_key(fmaf(time, ad.x, a.x), fmaf(time, ad.y, a.y), fmaf(time, ad.z, a.z),
+                                            a.w, ox, oy, oz, dx, dy, dz);
+            if (key < best) { best = key; idx = slot + k; }
+        }
+    }
+    return idx;
+}
+
+// ------------------------------------------------------------------ the f64 sphere test
+// shape.rs:35-65 / :101-133 verbatim in f64 on the fp32 inputs, unnormalised direction:
+// near root if t_min <= t < t_max else far root.  `clamp_disc`: the fp32 scan already decided
+// "hit", so a discriminant that f64 puts a hair below zero is a grazing hit, not a miss.
+__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double t_min, double t_max,
+                                               bool clamp_disc, double& t_out, double c_out[3]) {
+    const double tm = (double)r.time;
+    const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];
+    const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
+    const double cz = (double)S.c0z[id] + tm * (double)S.dcz[id];
+    const double rad = (double)S.rad[id];
+    const double ocx = (double)r.o.x - cx, ocy = (double)r.o.y - cy, ocz = (double)r.o.z - cz;
+    const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
+    const double a = dx * dx + dy * dy + dz * dz;
+    const double hb = ocx * dx + ocy * dy + ocz * dz;
+    const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
+    double disc = hb * hb - a * c;
+    if (clamp_disc) disc = fmax(disc, 0.0);
+    if (!(disc >= 0.0)) return false;
+    const double root = sqrt(disc);
+    double t = (-hb - root) / a;
+    bool ok = (t >= t_min) && (t < t_max);
+    if (!ok) {
+        t = (-hb + root) / a;
+        ok = (t >= t_min) && (t < t_max);
+    }
+    if (!ok) return false;
+    t_out = t;
+    c_out[0] = cx; c_out[1] = cy; c_out[2] = cz;
+    return true;
+}
+
+// HitList::hit(ray, t_min..inf) (hit.rs:100-110): closest hit over the whole world.
+__device__ __forceinline__ HitRec closest_hit(const DevScene& S, const LdsScene& L, const Ray& r, float t_min) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double t_best = inf, c_best[3] = {0, 0, 0};
+    int id_best = -1;
+    // (1) big spheres, f64, world order
+    for (int k = 0; k < S.n_big; ++k) {
+        double t, c[3];
+        const int id = S.big_id[k];
+        if (sphere_hit_f64(S, id, r, (double)t_min, t_best, false, t, c)) {
+            t_best = t; id_best = id;
+            c_best[0] = c[0]; c_best[1] = c[1]; c_best[2] = c[2];
+        }
+    }
+    // (2) fp32 scan of the LDS lists in the shifted, unit-direction frame
+    const float len2 = dot(r.d, r.d);
+    const float inv_len = 1.0f / sqrtf(len2);
+    const float len = len2 * inv_len;
+    const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
+    const float ox = fmaf(t_min, r.d.x, r.o.x), oy = fmaf(t_min, r.d.y, r.o.y), oz = fmaf(t_min, r.d.z, r.o.z);
+    uint32_t bound = kInfBits;
+    if (id_best >= 0) {
+        const float tb = (float)((t_best - (double)t_min) * (double)len);
+        bound = __float_as_uint(fmaxf(tb, 0.0f));
+    }
+    uint32_t best = bound;
+    int slot = -1;
+    scan_spheres(L, S.ns_pad, S.nm_pad, ox, oy, oz, dx, dy, dz, r.time, best, slot);
+    // (3) the winner of the scan, re-derived in f64 for the hit record
+    if (slot >= 0 && best < kInfBits) {
+        const int idx = resolve_slot(L, S.ns_pad, slot, ox, oy, oz, dx, dy, dz, r.time);
+        const int id = S.scan_id[idx];
+        double t, c[3];
+        if (sphere_hit_f64(S, id, r, (double)t_min, inf, true, t, c) && t < t_best) {
+            t_best = t; id_best = id;
+            c_best[0] = c[0]; c_best[1] = c[1]; c_best[2] = c[2];
+        }
+    }
+    HitRec h;
+    h.sphere = id_best;
+    if (id_best < 0) {
+        h.front = 0; h.t = 0.0f; h.p = {0, 0, 0}; h.n = {0, 0, 0};
+        return h;
+    }
+    // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
+    const double px = (double)r.o.x + t_best * (double)r.d.x;
+    const double py = (double)r.o.y + t_best * (double)r.d.y;
+    const double pz = (double)r.o.z + t_best * (double)r.d.z;
+    const double rad = (double)S.rad[id_best];
+    double nx = (px - c_best[0]) / rad, ny = (py - c_best[1]) / rad, nz = (pz - c_best[2]) / rad;
+    const bool front = ((double)r.d.x * nx + (double)r.d.y * ny + (double)r.d.z * nz) < 0.0;
+    if (!front) { nx = -nx; ny = -ny; nz = -nz; }
+    h.front = front ? 1 : 0;
+    h.t = (float)t_best;
+    h.p = {(float)px, (float)py, (float)pz};
+    h.n = {(float)nx, (float)ny, (float)nz};
+    return h;
+}
+
+// ------------------------------------------------------------------ textures
+__device__ __forceinline__ float lerpf(float t, float lo, float hi) { return lo * (1.0f - t) + hi * t; }  // lib.rs:46
+__device__ __forceinline__ float smoothf(float t) { return (t * t * t) * (t * (6.0f * t - 15.0f) + 10.0f); }  // lib.rs:50
+
+__device__ __forceinline__ int noise_hash(const rt_noise_table& tb, int x, int y, int z) {  // material.rs:309-313
+    return tb.perms[tb.perms[tb.perms[x] + y] + z];
+}
+__device__ __forceinline__ float perlin_grad(int h, float x, float y, float z) {  // material.rs:427-451 (the table)
+    h &= 15;
+    // first term: x for 0-7,12,13 else y (8,10 -> +y; 9,11,14,15 -> -y); second: y for 0-3,12,13 else z
+    const bool x_first = (h < 8) || h == 12 || h == 13;
+    const float a = x_first ? x : y;
+    const bool neg_a = x_first ? (h & 1) : !(h == 8 || h == 10);
+    const bool b_is_y = (h < 4) || h == 12 || h == 13;
+    const float b = b_is_y ? y : z;
+    bool neg_b;
+    if (h < 8) neg_b = (h & 2);
+    else if (h == 12 || h == 13) neg_b = false;
+    else neg_b = (h == 9 || h == 10 || h == 11 || h == 15);  // 8:+z 9:-z 10:-z 11:-z 14:+z 15:-z
+    return (neg_a ? -a : a) + (neg_b ? -b : b);
+}
+__device__ inline float noise_base(const rt_texture& tx, const rt_noise_table& tb, f3 p) {
+    p = p * tx.freq;
+    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
+    const float tx0 = p.x - fx, ty0 = p.y - fy, tz0 = p.z - fz;
+    const float sx = smoothf(tx0), sy = smoothf(ty0), sz = smoothf(tz0);
+    const int x0 = (int)fx & 255, y0 = (int)fy & 255, z0 = (int)fz & 255;
+    const int x1 = (x0 + 1) & 255, y1 = (y0 + 1) & 255, z1 = (z0 + 1) & 255;
+    float v000, v100, v010, v110, v001, v101, v011, v111;
+    if (tx.kind == RT_TEX_VALUE_NOISE) {  // material.rs:339-347
+        v000 = tb.randoms[noise_hash(tb, x0, y0, z0)]; v100 = tb.randoms[noise_hash(tb, x1, y0, z0)];
+        v010 = tb.randoms[noise_hash(tb, x0, y1, z0)]; v110 = tb.randoms[noise_hash(tb, x1, y1, z0)];
+        v001 = tb.randoms[noise_hash(tb, x0, y0, z1)]; v101 = tb.randoms[noise_hash(tb, x1, y0, z1)];
+        v011 = tb.randoms[noise_hash(tb, x0, y1, z1)]; v111 = tb.randoms[noise_hash(tb, x1, y1, z1)];
+    } else {  // material.rs:482-504
+        const float tx1 = tx0 - 1.0f, ty1 = ty0 - 1.0f, tz1 = tz0 - 1.0f;
+        v000 = perlin_grad(noise_hash(tb, x0, y0, z0), tx0, ty0, tz0);
+        v100 = perlin_grad(noise_hash(tb, x1, y0, z0), tx1, ty0, tz0);
+        v010 = perlin_grad(noise_hash(tb, x0, y1, z0), tx0, ty1, tz0);
+        v110 = perlin_grad(noise_hash(tb, x1, y1, z0), tx1, ty1, tz0);
+        v001 = perlin_grad(noise_hash(tb, x0, y0, z1), tx0, ty0, tz1);
+        v101 = perlin_grad(noise_hash(tb, x1, y0, z1), tx1, ty0, tz1);
+        v011 = perlin_grad(noise_hash(tb, x0, y1, z1), tx0, ty1, tz1);
+        v111 = perlin_grad(noise_hash(tb, x1, y1, z1), tx1, ty1, tz1);
+    }
+    const float x00 = lerpf(sx, v000, v100), x10 = lerpf(sx, v010, v110);
+    const float x01 = lerpf(sx, v001, v101), x11 = lerpf(sx, v011, v111);
+    const float ya = lerpf(sy, x00, x10), yb = lerpf(sy, x01, x11);
+    const float n = lerpf(sz, ya, yb);
+    return tx.kind == RT_TEX_VALUE_NOISE ? n : (n + 1.0f) * 0.5f;
+}
+__device__ inline float noise_eval(const DevTexture& T, const rt_noise_table* tables, f3 p) {
+    const rt_texture& tx = T.t;
+    const rt_noise_table& tb = tables[tx.table_id];
+    float v;
+    if (tx.op == RT_NOISE_PLAIN) {
+        v = noise_base(tx, tb, p);
+    } else {  // material.rs:192-203, :219-233
+        float sum = 0.0f, amp = 1.0f;
+        f3 q = p;
+        for (int l = 0; l < tx.layers; ++l) {
+            float nz = noise_base(tx, tb, q);
+            if (tx.op == RT_NOISE_TURBULENCE) nz = fabsf(2.0f * nz - 1.0f);
+            sum += nz * amp;
+            q = q * tx.lacunarity;
+            amp *= tx.gain;
+        }
+        v = sum / T.fractal_max;
+    }
+    if (tx.marbled) {  // material.rs:252-259
+        float n = tx.marble_gain * v + p.z;
+        n = tx.sin_freq * n + tx.phase;
+        v = (sinf(n) + 1.0f) * 0.5f;
+    }
+    return v;
+}
+__device__ inline f3 texture_value(const DevScene& S, const rt_noise_table* lds_tables, int tex_id, f3 p) {
+    const DevTexture& T = S.texs[tex_id];
+    const int kind = T.t.kind;
+    if (kind == RT_TEX_SOLID) return {T.t.color_a[0], T.t.color_a[1], T.t.color_a[2]};
+    if (kind == RT_TEX_CHECKER) {  // material.rs:155-165
+        const float f = T.t.freq;
+        bool parity = sinf(p.x * f) < 0.0f;
+        parity ^= sinf(p.y * f) < 0.0f;
+        parity ^= sinf(p.z * f) < 0.0f;
+        const float* c = parity ? T.t.color_a : T.t.color_b;
+        return {c[0], c[1], c[2]};
+    }
+    const float v = noise_eval(T, lds_tables, p);
+    return {v, v, v};
+}
+
+// ------------------------------------------------------------------ materials
+__device__ __forceinline__ f3 reflect_unit(f3 ud, f3 n) {  // vec3.rs:113-116 after its normalisation
+    const float k = 2.0f * dot(ud, n);
+    return {ud.x - k * n.x, ud.y - k * n.y, ud.z - k * n.z};
+}
+__device__ __forceinline__ float schlick(float cosv, float eta) {  // material.rs:84-88
+    float r0 = (1.0f - eta) / (1.0f + eta);
+    r0 *= r0;
+    const float m = 1.0f - cosv;
+    return r0 + (1.0f - r0) * (m * m * m * m * m);
+}
+// Material::scatter with explicit uniforms u0,u1.  Returns the albedo; `r` becomes the scattered ray.
+__device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables, const HitRec& h, Ray& r, float u0,
+                             float u1) {
+    const rt_material m = S.mats[S.mat_id[h.sphere]];
+    f3 albedo, dir;
+    if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
+        dir = h.n + map_unit_sphere(u0, u1);
+        if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard
+        albedo = texture_value(S, lds_tables, m.texture_id, h.p);
+    } else if (m.type == RT_MAT_METAL) {  // material.rs:61-72
+        const f3 fz = map_unit_sphere(u0, u1) * m.fuzz;
+        dir = reflect_unit(normalize(r.d), h.n) + fz;
+        if (dot(dir, h.n) <= 0.0f) dir = dir - fz * 2.0f;
+        albedo = {m.albedo[0], m.albedo[1], m.albedo[2]};
+    } else {  // material.rs:91-111
+        const float eta = h.front ? 1.0f / m.ior : m.ior;
+        const f3 ud = normalize(r.d);
+        const float cos_t = fminf(-dot(ud, h.n), 1.0f);
+        const float sin_t = sqrtf(1.0f - cos_t * cos_t);
+        if (eta * sin_t > 1.0f || u0 < schlick(cos_t, eta)) {
+            dir = reflect_unit(ud, h.n);  // reflect() re-normalises a unit vector: identity up to rounding
+        } else {  // vec3.rs:118-123; cos re-derived un-clamped as the reference does
+            const float c2 = -dot(ud, h.n);
+            const f3 par = (ud + h.n * c2) * eta;
+            const float k = sqrtf(fmaxf(0.0f, 1.0f - dot(par, par)));
+            dir = par - h.n * k;
+        }
+        albedo = {1.0f, 1.0f, 1.0f};
+    }
+    r.o = h.p;
+    r.d = dir;
+    return albedo;
+}
+
+// Camera::get_ray (screen.rs:79-94) with explicit uniforms.
+__device__ __forceinline__ Ray camera_ray(const rt_camera& c, float i, float j, float u0, float u1, float u2) {
+    f3 o = {c.origin[0], c.origin[1], c.origin[2]};
+    if (c.lens_radius != 0.0f) {
+        const f3 rd = map_unit_disk(u0, u1) * c.lens_radius;
+        o = {o.x + (rd.x * c.u[0] + rd.y * c.v[0]), o.y + (rd.x * c.u[1] + rd.y * c.v[1]),
+             o.z + (rd.x * c.u[2] + rd.y * c.v[2])};
+    }
+    Ray r;
+    r.o = o;
+    r.d = {c.lower_left[0] + i * c.horiz[0] + j * c.vert[0] - o.x, c.lower_left[1] + i * c.horiz[1] + j * c.vert[1] - o.y,
+           c.lower_left[2] + i * c.horiz[2] + j * c.vert[2] - o.z};
+    r.time = c.has_shutter ? u2 * (c.shutter_close - c.shutter_open) + c.shutter_open : 0.0f;
+    return r;
+}
+
+// sky gradient of main.rs:133-138
+__device__ __forceinline__ f3 sky(f3 d) {
+    const f3 ud = normalize(d);
+    const float t = 0.5f * (ud.y + 1.0f);
+    return {(1.0f - t) + t * 0.5f, (1.0f - t) + t * 0.7f, (1.0f - t) + t};
+}
+
+}  // namespace rtd

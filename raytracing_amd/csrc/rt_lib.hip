@@ -1,0 +1,720 @@
+// rt_lib.hip — kernels + C ABI (include/rtx_hip.h) of the MI355X path-tracing hot path.
+// gfx950 only.  Build: raytracing_amd/csrc/Makefile (hipcc --offload-arch=gfx950).
+//
+// Replaces reference main.rs:64-92 (rayon pixel/sample loop) + main.rs:110-139 (ray_color).
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rt_device.h"
+
+using namespace rtd;
+
+namespace {
+
+constexpr int kBlock = 256;          // 4 waves per workgroup share one LDS copy of the scene
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
+constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
+constexpr float kBigCenter = 500.0f;
+
+struct RenderArgs {
+    DevScene S;
+    rt_camera cam;
+    uint32_t W, H, tiles_x, n_tiles;
+    uint32_t spp_first;      // absolute index of this launch's first sample
+    uint32_t spp_count;      // samples per pixel in this launch
+    uint32_t spp_per_chunk;  // blockIdx.y picks [y*spp_per_chunk, ...) of them
+    uint32_t max_depth;
+    int32_t antialias;
+    uint32_t k0, k1;
+    float t_min;
+    uint32_t lds_scene_bytes;
+    unsigned long long* accum;  // W*H*3 fixed-point (2^-32) radiance sums
+    unsigned long long* rays;
+};
+
+// One wave = one 8x8 tile x one spp chunk.  The wave runs a private work queue of
+// (pixel, sample) items: a lane whose path ended takes the next item, so every lane has a live
+// ray in (almost) every pass of the sphere scan regardless of how path lengths differ.
+// Radiance is summed in 2^-32 fixed point (order-independent => bit-reproducible images
+// whatever the chunking, tiling or lane scheduling): LDS per wave, then one global atomic
+// per pixel-channel.
+__global__ __launch_bounds__(kBlock) void render_kernel(const RenderArgs A) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const LdsScene L = stage_scene(A.S, lds, tid, kBlock);
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes) + wave * 192;
+    acc[lane] = 0; acc[lane + 64] = 0; acc[lane + 128] = 0;
+
+    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
+    const uint32_t s_lo = blockIdx.y * A.spp_per_chunk;
+    const uint32_t s_n = (s_lo < A.spp_count) ? min(A.spp_per_chunk, A.spp_count - s_lo) : 0u;
+    uint32_t tx0 = 0, ty0 = 0, tw = 0, th = 0;
+    if (tile < A.n_tiles) {
+        tx0 = (tile % A.tiles_x) * kTile;
+        ty0 = (tile / A.tiles_x) * kTile;
+        tw = min((uint32_t)kTile, A.W - tx0);
+        th = min((uint32_t)kTile, A.H - ty0);
+    }
+    const uint32_t npix = tw * th;
+    const uint32_t total = npix * s_n;  // items of this wave
+    const float inv_w = 1.0f / ((float)A.W - 1.0f), inv_h = 1.0f / ((float)A.H - 1.0f);
+
+    uint32_t next = 0;
+    bool alive = false;
+    Ray ray = {{0, 0, 0}, {0, 0, 1}, 0};
+    f3 thr = {1, 1, 1};
+    uint32_t pix_local = 0, pix = 0, smp = 0, depth = 0;
+    unsigned long long n_rays = 0;
+
+    for (;;) {
+        // ---- refill dead lanes from the wave's queue
+        const unsigned long long need = __ballot(!alive);
+        if (!alive) {
+            const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
+                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+            if (item < total) {
+                const uint32_t s = item / npix;
+                pix_local = item - s * npix;
+                const uint32_t ly = pix_local / tw, lx = pix_local - ly * tw;
+                const uint32_t x = tx0 + lx, y = ty0 + ly;
+                pix = y * A.W + x;
+                smp = A.spp_first + s_lo + s;
+                uint32_t r0[4];
+                philox4x32_10(A.k0, A.k1, pix, smp, DIM_PIXEL, 0u, r0);
+                const float ri = A.antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
+                const float rj = A.antialias ? u01(r0[1]) : 0.0f;
+                const float ci = ((float)x + ri) * inv_w;           // main.rs:81
+                const float cj = 1.0f - ((float)y + rj) * inv_h;    // main.rs:82
+                float ut = 0.0f;
+                if (A.cam.has_shutter) {
+                    uint32_t r1[4];
+                    philox4x32_10(A.k0, A.k1, pix, smp, DIM_TIME, 0u, r1);
+                    ut = u01(r1[0]);
+                }
+                ray = camera_ray(A.cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
+                thr = {1.0f, 1.0f, 1.0f};
+                depth = 0;
+                alive = true;
+            }
+        }
+        next += (uint32_t)__popcll(need);
+        if (__ballot(alive) == 0ull) break;
+
+        // ---- one ray segment per live lane: closest hit, then scatter or terminate
+        if (alive) {
+            ++n_rays;
+            const HitRec h = closest_hit(A.S, L, ray, A.t_min);
+            bool done = false;
+            f3 rad = {0, 0, 0};
+            if (h.sphere < 0) {  // main.rs:133-138
+                rad = thr * sky(ray.d);
+                done = true;
+            } else {
+                uint32_t rb[4];
+                philox4x32_10(A.k0, A.k1, pix, smp, DIM_BOUNCE0 + depth, 0u, rb);
+                const f3 albedo = scatter(A.S, L.tables, h, ray, u01(rb[0]), u01(rb[1]));
+                thr = thr * albedo;  // main.rs:118
+                ++depth;
+                if (depth == A.max_depth) done = true;  // main.rs:126-130: black
+            }
+            if (done) {
+                alive = false;
+                const float c[3] = {rad.x, rad.y, rad.z};
+#pragma unroll
+                for (int k = 0; k < 3; ++k) {
+                    float v = c[k];
+                    v = (v > 0.0f) ? fminf(v, 1048576.0f) : 0.0f;  // NaN / negative -> 0
+                    const unsigned long long q = (unsigned long long)(v * kTwoPow32);
+                    if (q) atomicAdd(&acc[pix_local * 3 + k], q);
+                }
+            }
+        }
+    }
+
+    // ---- flush the wave's tile
+    __syncthreads();
+    if ((uint32_t)lane < npix && s_n) {
+        const uint32_t ly = lane / tw, lx = lane - ly * tw;
+        unsigned long long* g = A.accum + ((size_t)(ty0 + ly) * A.W + (tx0 + lx)) * 3;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const unsigned long long q = acc[lane * 3 + k];
+            if (q) atomicAdd(g + k, q);
+        }
+    }
+    // ray-segment counter: wave reduction, one atomic per wave
+    for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off, 64);
+    if (lane == 0 && n_rays) atomicAdd(A.rays, n_rays);
+}
+
+__global__ void finalize_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ out, size_t n,
+                                double scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (float)((double)accum[i] * scale);
+}
+
+// ---- fixed-batch kernels (parity entry points) --------------------------------------------
+__global__ __launch_bounds__(kBlock) void intersect_batch_kernel(const DevScene S, const rt_ray* __restrict__ rays,
+                                                                 uint32_t n, float t_min, rt_hit* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const rt_ray q = rays[i];
+    Ray r = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time};
+    const HitRec h = closest_hit(S, L, r, t_min);
+    rt_hit o;
+    memset(&o, 0, sizeof(o));
+    if (h.sphere >= 0) {
+        o.hit = 1;
+        o.sphere_id = h.sphere;
+        o.material_id = (int32_t)S.mat_id[h.sphere];
+        o.front_face = h.front;
+        o.t = h.t;
+        o.point[0] = h.p.x; o.point[1] = h.p.y; o.point[2] = h.p.z;
+        o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z;
+    }
+    out[i] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void scatter_batch_kernel(const DevScene S, const rt_ray* __restrict__ rays,
+                                                               const rt_hit* __restrict__ hits,
+                                                               const float* __restrict__ u4, uint32_t n,
+                                                               rt_scatter* __restrict__ out) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    rt_scatter o;
+    memset(&o, 0, sizeof(o));
+    const rt_hit hq = hits[i];
+    if (hq.hit) {
+        const rt_ray q = rays[i];
+        Ray r = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time};
+        HitRec h;
+        h.sphere = hq.sphere_id;
+        h.front = hq.front_face;
+        h.t = hq.t;
+        h.p = {hq.point[0], hq.point[1], hq.point[2]};
+        h.n = {hq.normal[0], hq.normal[1], hq.normal[2]};
+        const f3 a = scatter(S, L.tables, h, r, u4[4 * i], u4[4 * i + 1]);
+        o.scattered = 1;
+        o.albedo[0] = a.x; o.albedo[1] = a.y; o.albedo[2] = a.z;
+        o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
+        o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
+        o.time = r.time;
+    }
+    out[i] = o;
+}
+
+__global__ __launch_bounds__(kBlock) void texture_batch_kernel(const DevScene S, int tex_id,
+                                                               const float* __restrict__ p3, uint32_t n,
+                                                               float* __restrict__ out3) {
+    extern __shared__ __align__(16) unsigned char lds[];
+    const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const f3 c = texture_value(S, L.tables, tex_id, {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]});
+    out3[3 * i] = c.x; out3[3 * i + 1] = c.y; out3[3 * i + 2] = c.z;
+}
+
+__global__ void camera_rays_kernel(const rt_camera cam, const float* __restrict__ ij, const float* __restrict__ u4,
+                                   uint32_t n, rt_ray* __restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Ray r = camera_ray(cam, ij[2 * i], ij[2 * i + 1], u4[4 * i], u4[4 * i + 1], u4[4 * i + 2]);
+    rt_ray o;
+    o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
+    o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
+    o.time = r.time;
+    out[i] = o;
+}
+
+__global__ void rng_batch_kernel(uint32_t k0, uint32_t k1, const uint32_t* __restrict__ c4, uint32_t n,
+                                 uint32_t* __restrict__ out4) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r[4];
+    philox4x32_10(k0, k1, c4[4 * i], c4[4 * i + 1], c4[4 * i + 2], c4[4 * i + 3], r);
+    out4[4 * i] = r[0]; out4[4 * i + 1] = r[1]; out4[4 * i + 2] = r[2]; out4[4 * i + 3] = r[3];
+}
+
+// Screen::encode (screen.rs:26-45): gamma 2, x255.99, truncate, 0RGB.
+__global__ void encode_kernel(const float* __restrict__ rgb, uint32_t n, uint32_t* __restrict__ out,
+                              uint32_t* __restrict__ n_invalid) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float c[3] = {rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2]};
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+        if (!(c[k] >= 0.0f && c[k] <= 1.0f)) { bad = true; c[k] = (c[k] > 1.0f) ? 1.0f : 0.0f; }
+    if (bad) atomicAdd(n_invalid, 1u);
+    // f64 for the last step so truncation agrees with the reference's f64 arithmetic
+    const uint32_t r = (uint32_t)(255.99 * sqrt((double)c[0]));
+    const uint32_t g = (uint32_t)(255.99 * sqrt((double)c[1]));
+    const uint32_t b = (uint32_t)(255.99 * sqrt((double)c[2]));
+    out[i] = (r << 16) | (g << 8) | b;
+}
+
+thread_local std::string g_create_error;
+
+}  // namespace
+
+// ---------------------------------------------------------------------------------- context
+struct rt_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    std::string err;
+    // scene
+    bool has_scene = false;
+    DevScene S{};
+    std::vector<void*> scene_allocs;
+    size_t lds_scene = 0;
+    // render workspace
+    unsigned long long* accum = nullptr;
+    size_t accum_cap = 0;  // elements
+    unsigned long long* rays = nullptr;
+    float* out = nullptr;
+    size_t out_cap = 0;
+    int cu_count = 256;
+};
+
+namespace {
+
+int fail(rt_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    else g_create_error = msg;
+    return code;
+}
+#define RT_HIP(ctx, call)                                                                            \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess)                                                                        \
+            return fail(ctx, RT_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+template <class T>
+int dev_copy(rt_ctx* c, const T* host, size_t n, const T** out, bool track = true) {
+    void* d = nullptr;
+    const size_t bytes = (n ? n : 1) * sizeof(T);
+    RT_HIP(c, hipMalloc(&d, bytes));
+    if (track) c->scene_allocs.push_back(d);
+    if (n) RT_HIP(c, hipMemcpy(d, host, n * sizeof(T), hipMemcpyHostToDevice));
+    *out = static_cast<const T*>(d);
+    return RT_OK;
+}
+
+void free_scene(rt_ctx* c) {
+    for (void* p : c->scene_allocs) (void)hipFree(p);
+    c->scene_allocs.clear();
+    c->has_scene = false;
+}
+
+struct TmpBuf {  // device scratch for the batch entry points
+    void* p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+};
+
+size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
+
+int check_ready(rt_ctx* c) {
+    if (!c) return RT_ERR_BAD_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded (call rt_upload_scene first)");
+    return RT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rt_abi_version(void) { return RT_ABI_VERSION; }
+
+const char* rt_last_error(const rt_ctx* ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
+
+int rt_create(int device_ordinal, rt_ctx** out) {
+    if (!out) return fail(nullptr, RT_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return fail(nullptr, RT_ERR_NO_DEVICE, "no HIP device visible: this library has no CPU fallback");
+    if (device_ordinal < 0 || device_ordinal >= n)
+        return fail(nullptr, RT_ERR_BAD_ARG, "device ordinal out of range");
+    rt_ctx* c = new rt_ctx();
+    c->device = device_ordinal;
+    hipError_t e = hipSetDevice(device_ordinal);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev0);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev1);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev2);
+    if (e == hipSuccess) e = hipEventCreate(&c->ev3);
+    if (e == hipSuccess) e = hipMalloc((void**)&c->rays, sizeof(unsigned long long));
+    if (e != hipSuccess) {
+        g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
+        rt_destroy(c);
+        return RT_ERR_HIP;
+    }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) == hipSuccess) {
+        c->cu_count = prop.multiProcessorCount;
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+            g_create_error = std::string("rt_create: device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+            rt_destroy(c);
+            return RT_ERR_NO_DEVICE;
+        }
+    }
+    *out = c;
+    return RT_OK;
+}
+
+void rt_destroy(rt_ctx* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    free_scene(c);
+    if (c->accum) (void)hipFree(c->accum);
+    if (c->rays) (void)hipFree(c->rays);
+    if (c->out) (void)hipFree(c->out);
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->ev2) (void)hipEventDestroy(c->ev2);
+    if (c->ev3) (void)hipEventDestroy(c->ev3);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
+    if (!c || !s) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    RT_HIP(c, hipSetDevice(c->device));
+    if (s->n_spheres == 0) return fail(c, RT_ERR_BAD_ARG, "scene has no spheres");
+    if (s->n_spheres > RT_MAX_SPHERES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_SPHERES spheres");
+    if (s->n_materials == 0 || s->n_materials > RT_MAX_MATERIALS) return fail(c, RT_ERR_BAD_ARG, "bad n_materials");
+    if (s->n_textures > RT_MAX_TEXTURES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_TEXTURES textures");
+    if (s->n_noise_tables > RT_MAX_NOISE_TABLES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_NOISE_TABLES noise tables");
+    if (!s->c0x || !s->c0y || !s->c0z || !s->dcx || !s->dcy || !s->dcz || !s->radius || !s->material_id || !s->materials)
+        return fail(c, RT_ERR_BAD_ARG, "NULL scene array");
+    if ((s->n_textures && !s->textures) || (s->n_noise_tables && !s->noise_tables))
+        return fail(c, RT_ERR_BAD_ARG, "NULL texture / noise table array");
+    for (uint32_t i = 0; i < s->n_materials; ++i) {
+        const rt_material& m = s->materials[i];
+        if (m.type < RT_MAT_LAMBERTIAN || m.type > RT_MAT_DIELECTRIC) return fail(c, RT_ERR_BAD_ARG, "unknown material type");
+        if (m.type == RT_MAT_LAMBERTIAN && (m.texture_id < 0 || (uint32_t)m.texture_id >= s->n_textures))
+            return fail(c, RT_ERR_BAD_ARG, "Lambertian texture_id out of range");
+        if (m.type == RT_MAT_DIELECTRIC && !(m.ior > 0.0f)) return fail(c, RT_ERR_BAD_ARG, "Dielectric ior must be > 0");
+    }
+    std::vector<DevTexture> texs(s->n_textures);
+    for (uint32_t i = 0; i < s->n_textures; ++i) {
+        const rt_texture& t = s->textures[i];
+        if (t.kind < RT_TEX_SOLID || t.kind > RT_TEX_PERLIN_NOISE) return fail(c, RT_ERR_BAD_ARG, "unknown texture kind");
+        texs[i].t = t;
+        texs[i].fractal_max = 1.0f;
+        if (t.kind >= RT_TEX_VALUE_NOISE) {
+            if (t.table_id < 0 || (uint32_t)t.table_id >= s->n_noise_tables) return fail(c, RT_ERR_BAD_ARG, "noise table_id out of range");
+            if (t.op < RT_NOISE_PLAIN || t.op > RT_NOISE_TURBULENCE) return fail(c, RT_ERR_BAD_ARG, "unknown noise op");
+            if (t.op != RT_NOISE_PLAIN) {
+                // the asserts of material.rs:185-186 / :212-213
+                if (t.layers <= 0) return fail(c, RT_ERR_BAD_ARG, "fBm: Can't have 0 layers.");
+                if (!(0.0f < t.gain && t.gain < 1.0f)) return fail(c, RT_ERR_BAD_ARG, "fBm: Gain must be in range (0, 1).");
+                double g = t.gain, pw = 1.0;
+                for (int l = 0; l < t.layers; ++l) pw *= g;
+                texs[i].fractal_max = (float)((1.0 - pw) / (1.0 - g));
+            }
+        }
+    }
+    for (uint32_t t = 0; t < s->n_noise_tables; ++t)
+        for (int i = 0; i < 512; ++i)
+            if (s->noise_tables[t].perms[i] > 255) return fail(c, RT_ERR_BAD_ARG, "noise perms entry > 255");
+
+    std::vector<float4> stat, mov_a, mov_b;
+    std::vector<int32_t> stat_id, mov_id, big_id;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        if (s->material_id[i] >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "sphere material_id out of range");
+        const float r = s->radius[i];
+        if (!(r > 0.0f) || !std::isfinite(r)) return fail(c, RT_ERR_BAD_ARG, "sphere radius must be finite and > 0");
+        const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
+        const float cm = std::fmax(std::fmax(std::fabs(s->c0x[i]), std::fabs(s->c0y[i])), std::fabs(s->c0z[i]));
+        if (r >= kBigRadius || cm >= kBigCenter) {
+            big_id.push_back((int32_t)i);
+        } else if (moving) {
+            mov_a.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], r * r));
+            mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
+            mov_id.push_back((int32_t)i);
+        } else {
+            stat.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], r * r));
+            stat_id.push_back((int32_t)i);
+        }
+    }
+    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, -1.0f)); stat_id.push_back(-1); }
+    while (mov_a.size() % kChunk) {
+        mov_a.push_back(make_float4(0, 0, 0, -1.0f));
+        mov_b.push_back(make_float4(0, 0, 0, 0));
+        mov_id.push_back(-1);
+    }
+    std::vector<int32_t> scan_id(stat_id);
+    scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
+    const size_t lds_need = lds_scene_bytes((int)stat.size(), (int)mov_a.size(), (int)s->n_noise_tables);
+    if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
+
+    free_scene(c);
+    DevScene D{};
+    int rc;
+#define UP(expr) if ((rc = (expr)) != RT_OK) { free_scene(c); return rc; }
+    UP(dev_copy(c, stat.data(), stat.size(), &D.stat));
+    UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.mov_a));
+    UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.mov_b));
+    UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
+    UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
+    UP(dev_copy(c, s->c0x, (size_t)s->n_spheres, &D.c0x));
+    UP(dev_copy(c, s->c0y, (size_t)s->n_spheres, &D.c0y));
+    UP(dev_copy(c, s->c0z, (size_t)s->n_spheres, &D.c0z));
+    UP(dev_copy(c, s->dcx, (size_t)s->n_spheres, &D.dcx));
+    UP(dev_copy(c, s->dcy, (size_t)s->n_spheres, &D.dcy));
+    UP(dev_copy(c, s->dcz, (size_t)s->n_spheres, &D.dcz));
+    UP(dev_copy(c, s->radius, (size_t)s->n_spheres, &D.rad));
+    UP(dev_copy(c, s->material_id, (size_t)s->n_spheres, &D.mat_id));
+    UP(dev_copy(c, s->materials, (size_t)s->n_materials, &D.mats));
+    UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
+    UP(dev_copy(c, s->noise_tables, (size_t)s->n_noise_tables, &D.tables));
+#undef UP
+    D.ns_pad = (int32_t)stat.size();
+    D.nm_pad = (int32_t)mov_a.size();
+    D.n_big = (int32_t)big_id.size();
+    D.n_tables = (int32_t)s->n_noise_tables;
+    D.n_spheres = (int32_t)s->n_spheres;
+    D.n_textures = (int32_t)s->n_textures;
+    c->S = D;
+    c->lds_scene = align16(lds_need);
+    c->has_scene = true;
+    return RT_OK;
+}
+
+static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* d_out, bool mean,
+                         rt_stats* stats) {
+    int rc = check_ready(c);
+    if (rc != RT_OK) return rc;
+    if (!cam || !p || !d_out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    if (p->width < 2 || p->height < 2) return fail(c, RT_ERR_BAD_ARG, "width and height must be >= 2 (i = x/(W-1), main.rs:81)");
+    if (p->spp == 0 || p->max_depth == 0) return fail(c, RT_ERR_BAD_ARG, "spp and max_depth are NonZero in the reference (config.rs:52,56)");
+    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(c, RT_ERR_BAD_ARG, "image too large");
+    if ((uint64_t)p->spp_offset + p->spp > 0xFFFFFFFFull) return fail(c, RT_ERR_BAD_ARG, "spp_offset + spp overflows 32 bits");
+    if (!(p->t_min >= 0.0f)) return fail(c, RT_ERR_BAD_ARG, "t_min must be >= 0");
+
+    const size_t n_px = (size_t)p->width * p->height, n_el = n_px * 3;
+    if (c->accum_cap < n_el) {
+        if (c->accum) (void)hipFree(c->accum);
+        c->accum = nullptr; c->accum_cap = 0;
+        if (hipMalloc((void**)&c->accum, n_el * sizeof(unsigned long long)) != hipSuccess)
+            return fail(c, RT_ERR_ALLOC, "cannot allocate the radiance accumulators");
+        c->accum_cap = n_el;
+    }
+    RT_HIP(c, hipEventRecord(c->ev0, c->stream));
+    RT_HIP(c, hipMemsetAsync(c->accum, 0, n_el * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(c->rays, 0, sizeof(unsigned long long), c->stream));
+
+    RenderArgs A{};
+    A.S = c->S;
+    A.cam = *cam;
+    A.W = p->width; A.H = p->height;
+    A.tiles_x = (p->width + kTile - 1) / kTile;
+    A.n_tiles = A.tiles_x * ((p->height + kTile - 1) / kTile);
+    A.max_depth = p->max_depth;
+    A.antialias = p->antialias;
+    A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
+    A.t_min = p->t_min;
+    A.lds_scene_bytes = (uint32_t)c->lds_scene;
+    A.accum = c->accum;
+    A.rays = c->rays;
+    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
+
+    // Launch plan.  A launch renders `spp_l` samples per pixel as grid (tile groups, chunks).
+    // Chunks keep the grid at >= ~48 waves per SIMD-slot so the tail of the last tiles is short;
+    // launches are capped at 2^31 samples so no single kernel runs for minutes.
+    const uint32_t blocks_x = (A.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    const uint64_t max_samples_per_launch = 1ull << 31;
+    uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
+    const uint64_t target_waves = (uint64_t)c->cu_count * 16 * 12;
+    uint32_t done = 0, launches = 0;
+    RT_HIP(c, hipEventRecord(c->ev1, c->stream));
+    while (done < p->spp) {
+        const uint32_t spp_l = std::min(spp_per_launch, p->spp - done);
+        uint32_t chunks = (uint32_t)std::min<uint64_t>(spp_l, (target_waves + A.n_tiles - 1) / A.n_tiles);
+        chunks = std::max(1u, std::min(chunks, 65535u));
+        A.spp_first = p->spp_offset + done;
+        A.spp_count = spp_l;
+        A.spp_per_chunk = (spp_l + chunks - 1) / chunks;
+        chunks = (spp_l + A.spp_per_chunk - 1) / A.spp_per_chunk;
+        hipLaunchKernelGGL(render_kernel, dim3(blocks_x, chunks), dim3(kBlock), lds_bytes, c->stream, A);
+        RT_HIP(c, hipGetLastError());
+        done += spp_l;
+        ++launches;
+    }
+    RT_HIP(c, hipEventRecord(c->ev2, c->stream));
+    const double scale = (1.0 / 4294967296.0) / (mean ? (double)p->spp : 1.0);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream, c->accum, d_out, n_el, scale);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipEventRecord(c->ev3, c->stream));
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    if (stats) {
+        std::memset(stats, 0, sizeof(*stats));
+        unsigned long long nr = 0;
+        RT_HIP(c, hipMemcpy(&nr, c->rays, sizeof(nr), hipMemcpyDeviceToHost));
+        stats->rays_traced = nr;
+        stats->samples = (uint64_t)n_px * p->spp;
+        RT_HIP(c, hipEventElapsedTime(&stats->kernel_ms, c->ev1, c->ev2));
+        RT_HIP(c, hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
+        stats->n_launches = launches;
+    }
+    return RT_OK;
+}
+
+int rt_render_accum_device(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* d_sum_rgb, rt_stats* stats) {
+    return render_common(c, cam, p, d_sum_rgb, false, stats);
+}
+
+int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rgb, rt_stats* stats) {
+    if (!c || !p || !out_rgb) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    RT_HIP(c, hipSetDevice(c->device));
+    const size_t n_el = (size_t)p->width * p->height * 3;
+    if (c->out_cap < n_el) {
+        if (c->out) (void)hipFree(c->out);
+        c->out = nullptr; c->out_cap = 0;
+        if (hipMalloc((void**)&c->out, std::max<size_t>(n_el, 1) * sizeof(float)) != hipSuccess)
+            return fail(c, RT_ERR_ALLOC, "cannot allocate the output image");
+        c->out_cap = n_el;
+    }
+    int rc = render_common(c, cam, p, c->out, true, stats);
+    if (rc != RT_OK) return rc;
+    RT_HIP(c, hipMemcpy(out_rgb, c->out, n_el * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---- batch entry points ---------------------------------------------------------------------
+#define RT_TMP(ctx, buf, bytes) RT_HIP(ctx, hipMalloc(&(buf).p, (bytes) ? (bytes) : 1))
+
+int rt_intersect_batch(rt_ctx* c, const rt_ray* rays, uint32_t n, float t_min, rt_hit* out) {
+    int rc = check_ready(c);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (!rays || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    TmpBuf dr, dh;
+    RT_TMP(c, dr, n * sizeof(rt_ray));
+    RT_TMP(c, dh, n * sizeof(rt_hit));
+    RT_HIP(c, hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(intersect_batch_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), c->lds_scene, c->stream,
+                       c->S, (const rt_ray*)dr.p, n, t_min, (rt_hit*)dh.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out, dh.p, n * sizeof(rt_hit), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_scatter_batch(rt_ctx* c, const rt_ray* rays, const rt_hit* hits, const float* u4, uint32_t n, rt_scatter* out) {
+    int rc = check_ready(c);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (!rays || !hits || !u4 || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    for (uint32_t i = 0; i < n; ++i)
+        if (hits[i].hit && (hits[i].sphere_id < 0 || hits[i].sphere_id >= c->S.n_spheres))
+            return fail(c, RT_ERR_BAD_ARG, "hit.sphere_id out of range");
+    TmpBuf dr, dh, du, dout;
+    RT_TMP(c, dr, n * sizeof(rt_ray));
+    RT_TMP(c, dh, n * sizeof(rt_hit));
+    RT_TMP(c, du, n * 4 * sizeof(float));
+    RT_TMP(c, dout, n * sizeof(rt_scatter));
+    RT_HIP(c, hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(dh.p, hits, n * sizeof(rt_hit), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(du.p, u4, n * 4 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(scatter_batch_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), c->lds_scene, c->stream,
+                       c->S, (const rt_ray*)dr.p, (const rt_hit*)dh.p, (const float*)du.p, n, (rt_scatter*)dout.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out, dout.p, n * sizeof(rt_scatter), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_texture_batch(rt_ctx* c, int32_t tex_id, const float* p3, uint32_t n, float* out3) {
+    int rc = check_ready(c);
+    if (rc != RT_OK) return rc;
+    if (n == 0) return RT_OK;
+    if (!p3 || !out3) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    TmpBuf dp, dout;
+    RT_TMP(c, dp, n * 3 * sizeof(float));
+    RT_TMP(c, dout, n * 3 * sizeof(float));
+    if (tex_id < 0 || tex_id >= c->S.n_textures) return fail(c, RT_ERR_BAD_ARG, "texture_id out of range");
+    RT_HIP(c, hipMemcpy(dp.p, p3, n * 3 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(texture_batch_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), c->lds_scene, c->stream,
+                       c->S, tex_id, (const float*)dp.p, n, (float*)dout.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out3, dout.p, n * 3 * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_camera_rays(rt_ctx* c, const rt_camera* cam, const float* ij2, const float* u4, uint32_t n, rt_ray* out) {
+    if (!c) return RT_ERR_BAD_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (n == 0) return RT_OK;
+    if (!cam || !ij2 || !u4 || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    TmpBuf dij, du, dout;
+    RT_TMP(c, dij, n * 2 * sizeof(float));
+    RT_TMP(c, du, n * 4 * sizeof(float));
+    RT_TMP(c, dout, n * sizeof(rt_ray));
+    RT_HIP(c, hipMemcpy(dij.p, ij2, n * 2 * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemcpy(du.p, u4, n * 4 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(camera_rays_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, *cam, (const float*)dij.p,
+                       (const float*)du.p, n, (rt_ray*)dout.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out, dout.p, n * sizeof(rt_ray), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_rng_batch(rt_ctx* c, uint64_t seed, const uint32_t* c4, uint32_t n, uint32_t* out4) {
+    if (!c) return RT_ERR_BAD_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (n == 0) return RT_OK;
+    if (!c4 || !out4) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    TmpBuf dc, dout;
+    RT_TMP(c, dc, n * 4 * sizeof(uint32_t));
+    RT_TMP(c, dout, n * 4 * sizeof(uint32_t));
+    RT_HIP(c, hipMemcpy(dc.p, c4, n * 4 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(rng_batch_kernel, dim3((n + 255) / 256), dim3(256), 0, c->stream, (uint32_t)seed,
+                       (uint32_t)(seed >> 32), (const uint32_t*)dc.p, n, (uint32_t*)dout.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out4, dout.p, n * 4 * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+int rt_encode(rt_ctx* c, const float* rgb, uint32_t n_pixels, uint32_t* out_0rgb, uint32_t* n_invalid) {
+    if (!c) return RT_ERR_BAD_ARG;
+    RT_HIP(c, hipSetDevice(c->device));
+    if (n_invalid) *n_invalid = 0;
+    if (n_pixels == 0) return RT_OK;
+    if (!rgb || !out_0rgb) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    TmpBuf din, dout, dcnt;
+    RT_TMP(c, din, (size_t)n_pixels * 3 * sizeof(float));
+    RT_TMP(c, dout, (size_t)n_pixels * sizeof(uint32_t));
+    RT_TMP(c, dcnt, sizeof(uint32_t));
+    RT_HIP(c, hipMemcpy(din.p, rgb, (size_t)n_pixels * 3 * sizeof(float), hipMemcpyHostToDevice));
+    RT_HIP(c, hipMemsetAsync(dcnt.p, 0, sizeof(uint32_t), c->stream));
+    hipLaunchKernelGGL(encode_kernel, dim3((n_pixels + 255) / 256), dim3(256), 0, c->stream, (const float*)din.p,
+                       n_pixels, (uint32_t*)dout.p, (uint32_t*)dcnt.p);
+    RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipStreamSynchronize(c->stream));
+    RT_HIP(c, hipMemcpy(out_0rgb, dout.p, (size_t)n_pixels * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    uint32_t cnt = 0;
+    RT_HIP(c, hipMemcpy(&cnt, dcnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (n_invalid) *n_invalid = cnt;
+    return RT_OK;
+}
+
+}  // extern "C"
