@@ -95,7 +95,7 @@ void orc_pcg_unit_disk(uint64_t seed, uint32_t n, double* out3) {
 
 // Decision margin of one ray (f64): the smallest of
 //   (a) |r^2 - l^2| / r^2 over all spheres (l = distance of the line from the centre): grazing,
-//   (b) |t_root - t_min| * |d| / r over all real roots: a root sitting on the t_min boundary,
+//   (b) |t_root / t_min - 1| over all real roots: a root sitting on the t_min boundary,
 //   (c) (t_2nd - t_best) * |d| / max(t_best * |d|, r_best): closest vs runner-up.
 // A ray whose margin is below the test's epsilon can legitimately flip hit/miss or
 // sphere id between f64 and fp32 arithmetic and is excluded from bit-exact checks.
@@ -115,7 +115,7 @@ static double decision_margin(const Scene<double>& sc, const Ray<double>& ray, d
             double ts[2] = {(-hb - root) / a, (-hb + root) / a};
             double tv = -1;
             for (double t : ts) {
-                m = std::min(m, std::fabs(t - t_min) * len / s.radius);
+                m = std::min(m, std::fabs(t / t_min - 1.0));
                 if (tv < 0 && t >= t_min) tv = t;
             }
             if (tv >= 0) {

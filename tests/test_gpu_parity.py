@@ -1,0 +1,262 @@
+"""GPU parity tests: the HIP path (through the C ABI, librtx_hip.so) against the committed golden vectors
+and, where sizes allow, against the CPU oracle run live on the same inputs.
+
+north_star's two checks:
+  (1) fixed ray batches: hit/miss, sphere id, material id, front_face BIT-EXACT; t, normal, scatter
+      direction within 1e-5 relative.  Rays whose f64 decision margin (oracle_capi.cpp::decision_margin:
+      grazing, root on the t_min boundary, near-tie between two spheres) is below EPS_MARGIN are excluded
+      and counted — an fp32 scan cannot be bit-exact with f64 inside that band (SURVEY.md §7 "hard parts").
+  (2) converged images within an RMSE tolerance after gamma.
+"""
+import numpy as np
+import pytest
+
+from conftest import golden, rmse_gamma
+from helpers import check_hits, rel_err, scene_checksum
+
+pytestmark = pytest.mark.gpu
+
+EPS_MARGIN = 1e-3  # relative decision margin below which a ray is excluded from the bit-exact checks
+TOL = 1e-5         # north_star: t, normal, scatter direction within 1e-5 relative
+
+
+def test_rng_matches_oracle_and_random123(ctx, orc):
+    g = golden("philox.npz")
+    assert np.array_equal(ctx.rng_batch(int(g["seed"]), g["counters"]), g["out"])
+    kat = ctx.rng_batch(0x299F31D0A4093822, np.array([[0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344]], np.uint32))
+    assert [int(x) for x in kat[0]] == [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]
+    c = np.random.default_rng(7).integers(0, 2**32, (100000, 4), dtype=np.uint32)
+    assert np.array_equal(ctx.rng_batch(0xDEADBEEFCAFEF00D, c), orc.philox(0xDEADBEEFCAFEF00D, c))
+
+
+def test_camera_rays(ctx, api):
+    g = golden("camera_Random.npz")
+    w = api.World("Random", seed=1, aspect=1200 / 800)
+    assert scene_checksum(api, w) == str(g["checksum"])
+    r = ctx.camera_rays(w.camera, g["ij"], g["u"])
+    e = g["rays"]
+    assert rel_err(r["origin"], e["origin"]).max() < TOL
+    assert rel_err(r["dir"], e["dir"]).max() < TOL
+    assert np.abs(r["time"] - e["time"]).max() < 1e-6
+    assert len(ctx.camera_rays(w.camera, np.zeros((0, 2)), np.zeros((0, 4)))) == 0
+
+
+@pytest.mark.parametrize("name", ["FinalStatic", "Random", "Balls"])
+@pytest.mark.parametrize("case", ["primary", "secondary", "grazing", "inside"])
+def test_intersect_batches(ctx, api, name, case):
+    g = golden(f"rays_{name}.npz")
+    w = api.World(name, seed=1, aspect=1200 / 800)
+    assert scene_checksum(api, w) == str(g["checksum"])
+    ctx.upload(w.scene)
+    got = ctx.intersect_batch(g[f"{case}_rays"], 1e-3)
+    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL)
+    print(name, case, stats)
+    miss = got["hit"] == 0
+    assert not got["t"][miss].any() and not got["normal"][miss].any()  # a miss is all zeros
+
+
+def test_intersect_edge_cases(ctx, api, orc):
+    w = api.World("Balls", seed=1)
+    ctx.upload(w.scene)
+    assert len(ctx.intersect_batch(np.zeros(0, api.ray_dtype))) == 0  # empty batch
+    r = np.zeros(5, api.ray_dtype)
+    r["origin"] = [[0, 0, 1], [0, 0, -0.5], [0, 0, -1], [0, 5, -1], [0, -0.4999, -1]]
+    r["dir"] = [[0, 0, 1], [0, 0, 1], [0, 0, 7], [0, -2, 0], [0, -1e-3, 0]]
+    got = ctx.intersect_batch(r)
+    exp = orc.intersect_batch(w.scene, r)
+    assert got["hit"].tolist() == exp["hit"].tolist() == [0, 0, 1, 1, 1]
+    assert got["sphere_id"].tolist() == exp["sphere_id"].tolist()
+    assert got["front_face"].tolist() == exp["front_face"].tolist()
+    assert rel_err(got["t"][2:], exp["t"][2:]).max() < TOL
+    # a ragged batch size (not a multiple of the 256-thread workgroup, nor of a wave)
+    g = golden("rays_Balls.npz")
+    rays = g["primary_rays"][:1237]
+    check_hits(ctx.intersect_batch(rays), g["primary_hits"][:1237], EPS_MARGIN, TOL)
+    # errors: no scene on a fresh context; NULL-size misuse is reported, not crashed on
+    c2 = api.Context(0)
+    with pytest.raises(api.RtError) as e:
+        c2.intersect_batch(rays)
+    assert e.value.code == api.RT_ERR_NO_SCENE
+    c2.close()
+
+
+@pytest.mark.parametrize("name", ["FinalStatic", "Random", "Balls"])
+def test_scatter_batches(ctx, api, name):
+    g = golden(f"rays_{name}.npz")
+    w = api.World(name, seed=1, aspect=1200 / 800)
+    ctx.upload(w.scene)
+    s = w.scene
+    mats = np.array([s.materials[i].type for i in range(s.n_materials)])
+    for pre in ("scatter", "scatter_in", "scatter_gz"):
+        rays, hits, u, exp = g[f"{pre}_rays"], g[f"{pre}_hits"], g[f"{pre}_u"], g[f"{pre}_out"]
+        got = ctx.scatter_batch(rays, hits, u)
+        m = hits["hit"] == 1
+        assert np.array_equal(got["scattered"], exp["scattered"])
+        assert not got["dir"][~m].any()
+        # branch decisions (Schlick coin / TIR / metal below-surface) can flip for rays within rounding
+        # of the decision boundary: compare directions, count large deviations, allow a handful
+        err = rel_err(got["dir"][m], exp["dir"][m], floor=1e-3)
+        bad = err > TOL
+        # a Lambertian n + S that nearly cancels has an ill-conditioned direction: relative to |n| = 1 instead
+        abs_err = np.linalg.norm(got["dir"][m].astype(np.float64) - exp["dir"][m], axis=1)
+        bad &= abs_err > TOL
+        assert bad.sum() <= max(2, 2e-3 * m.sum()), (name, pre, int(bad.sum()), float(err.max()))
+        assert np.abs(got["albedo"][m] - exp["albedo"][m]).max() < 1e-6 or name == "Random"
+        if name == "Random":  # checker ground: sin(10 x) sign can flip within rounding of a zero crossing
+            assert (np.abs(got["albedo"][m] - exp["albedo"][m]).max(1) > 1e-6).sum() <= 3
+        assert rel_err(got["origin"][m], exp["origin"][m]).max() < TOL
+        assert np.array_equal(got["time"][m], exp["time"][m].astype(np.float32))
+        kinds = set(mats[hits["material_id"][m]].tolist())
+        print(name, pre, "materials", kinds, "max rel err", float(err.max()), "bad", int(bad.sum()))
+
+
+def test_textures_all_noise_scenes(ctx, api):
+    g = golden("textures.npz")
+    pts = g["points"]
+    for name in ["ValueNoise1", "ValueNoise2", "ValueNoisePink", "ValueTurbulence", "ValueMarbled", "PerlinNoise1",
+                 "PerlinNoise2", "PerlinNoisePink", "PerlinTurbulence", "PerlinMarbled", "Random", "BirdsEyeView"]:
+        w = api.World(name, seed=1)
+        assert scene_checksum(api, w) == str(g[f"{name}_checksum"])
+        ctx.upload(w.scene)
+        got = ctx.texture_batch(int(g[f"{name}_tex_id"]), pts)
+        exp = g[f"{name}_values"]
+        # |p| <= 12: lattice coordinates are exact enough in fp32 for the same cell to be chosen.
+        # the +-1000 block multiplies by freq*lacunarity^k: fp32 lattice position error ~1e-4..1e-2 of a cell
+        near = np.abs(pts).max(1) <= 12.5
+        err = np.abs(got - exp).max(1)
+        if name in ("Random", "BirdsEyeView"):  # checker: exact colours unless sin() sits on a zero crossing
+            assert (err[near] > 1e-6).sum() <= 2, name
+        else:
+            tol = 2e-4 if "Marbled" not in name and "Turb" not in name and "Pink" not in name else 2e-3
+            assert err[near].max() < tol, (name, float(err[near].max()))
+            assert np.all((got >= 0) & (got <= 1)), name
+        print(name, "max err near", float(err[near].max()), "far", float(err[~near].max()))
+    with pytest.raises(api.RtError):
+        ctx.texture_batch(9999, pts)
+
+
+def test_render_path_level_parity_small(ctx, api):
+    """Same counter RNG + same maps => the GPU image follows the oracle's sample for sample; only rays whose
+    fp32 decisions flip differ. 100x56 @ 16 spp against the committed oracle image."""
+    g = golden("images.npz")
+    w = api.World("FinalStatic", seed=1, aspect=100 / 56)
+    assert scene_checksum(api, w) == str(g["FinalStatic16_checksum"])
+    ctx.upload(w.scene)
+    p = api.make_params(100, 56, 16, seed=w.render_seed)
+    img, st = ctx.render(w.camera, p)
+    ref = g["FinalStatic16_img"]
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1.0
+    assert st.samples == 100 * 56 * 16
+    assert abs(int(st.rays_traced) - int(g["FinalStatic16_rays"])) < 0.005 * int(g["FinalStatic16_rays"])
+    r = rmse_gamma(img, ref)
+    assert r < 0.01, r  # MC noise at 16 spp would be ~0.1: this is path-level agreement
+    assert np.median(np.abs(img - ref)) < 1e-5
+
+
+@pytest.mark.parametrize("name,tol", [("FinalStatic", 0.004), ("Random", 0.004), ("PerlinMarbled", 0.004),
+                                      ("PerlinTurbulence", 0.006), ("TwoSpheres", 0.006)])
+def test_render_converged_rmse_after_gamma(ctx, api, name, tol):
+    """north_star check (2): the converged image matches the reference CPU render (oracle, f64, BVH) within an
+    RMSE tolerance after gamma. Tolerances are ~10x below the visible threshold (1/255 = 0.0039 per level)."""
+    g = golden("images.npz")
+    W, H, spp = (int(x) for x in g[f"{name}_shape"])
+    w = api.World(name, seed=1, aspect=W / H)
+    assert scene_checksum(api, w) == str(g[f"{name}_checksum"])
+    ctx.upload(w.scene)
+    p = api.make_params(W, H, spp, seed=int(g[f"{name}_seed"]))
+    img, st = ctx.render(w.camera, p)
+    ref = g[f"{name}_img"]
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1.0
+    r = rmse_gamma(img, ref)
+    rays_rel = abs(int(st.rays_traced) - int(g[f"{name}_rays"])) / int(g[f"{name}_rays"])
+    print(name, "rmse(gamma)", r, "rays rel diff", rays_rel, "kernel_ms", st.kernel_ms)
+    assert r < tol, (name, r)
+    assert rays_rel < 0.003
+    enc, bad = ctx.encode(img)  # Screen::encode (screen.rs:26-45) on the device
+    assert bad == 0
+    exp_enc = ((255.99 * np.sqrt(img.astype(np.float64))).astype(np.uint32) * [65536, 256, 1]).sum(-1).reshape(-1)
+    assert np.array_equal(enc, exp_enc.astype(np.uint32))
+
+
+def test_render_properties_full_size(ctx, api):
+    """Size-independent properties at BASELINE config-2 geometry (1200x800, reduced spp to keep the test short):
+    determinism, spp-partition additivity (what the multi-GPU split relies on), chunking invariance,
+    no-antialias mode, every pixel finite and in [0,1] (the reference's encode would panic otherwise)."""
+    w = api.World("FinalStatic", seed=1, aspect=1200 / 800)
+    ctx.upload(w.scene)
+    p = api.make_params(1200, 800, 8, seed=w.render_seed)
+    a, sa = ctx.render(w.camera, p)
+    b, sb = ctx.render(w.camera, p)
+    assert np.array_equal(a, b) and sa.rays_traced == sb.rays_traced  # bit-reproducible (fixed-point sums)
+    assert np.isfinite(a).all() and a.min() >= 0 and a.max() <= 1
+    lo, _ = ctx.render(w.camera, api.make_params(1200, 800, 3, seed=w.render_seed))
+    hi, _ = ctx.render(w.camera, api.make_params(1200, 800, 5, seed=w.render_seed, spp_offset=3))
+    whole = (3 * lo.astype(np.float64) + 5 * hi.astype(np.float64)) / 8
+    assert np.abs(whole - a).max() < 2e-7  # same samples, summed in another order and rounded once more
+    assert 2.0 < sa.rays_traced / sa.samples < 4.0
+    n, _ = ctx.render(w.camera, api.make_params(1200, 800, 2, seed=w.render_seed, antialias=False))
+    assert np.isfinite(n).all()
+    # ragged image: width/height not multiples of the 8x8 tile, 2 px minimum
+    for (W, H) in ((37, 19), (8, 2), (2, 2)):
+        wr = api.World("FinalStatic", seed=1, aspect=W / H)
+        img, st = ctx.render(wr.camera, api.make_params(W, H, 4, seed=1))
+        assert img.shape == (H, W, 3) and np.isfinite(img).all() and st.samples == W * H * 4
+        assert img.sum() > 0
+    # argument errors
+    for bad in (dict(width=1), dict(spp=0), dict(max_depth=0)):
+        kw = dict(width=16, height=16, spp=1, max_depth=5)
+        kw.update(bad)
+        with pytest.raises(api.RtError) as e:
+            ctx.render(w.camera, api.make_params(kw["width"], kw["height"], kw["spp"], max_depth=kw["max_depth"]))
+        assert e.value.code == api.RT_ERR_BAD_ARG
+
+
+def test_max_depth_semantics(ctx, api, orc):
+    """main.rs:126-130: a path that still hits after max_depth bounces is black. TwoSpheres (camera between two
+    huge checker spheres) keeps bouncing, so depth matters: compare a depth sweep against the oracle."""
+    w = api.World("TwoSpheres", seed=1, aspect=64 / 36)
+    ctx.upload(w.scene)
+    prev = None
+    for depth in (1, 2, 5, 50):
+        p = api.make_params(64, 36, 64, max_depth=depth, seed=5)
+        img, st = ctx.render(w.camera, p)
+        ref, _, rays = orc.render(w.scene, w.camera, p, n_threads=8)
+        assert rmse_gamma(img, ref) < 0.01, depth
+        assert abs(int(st.rays_traced) - rays) <= 0.003 * rays
+        if prev is not None:
+            assert img.mean() >= prev - 1e-3  # more bounces never darken
+        prev = img.mean()
+
+
+def test_upload_validation(api):
+    c = api.Context(0)
+    w = api.World("Balls", seed=1)
+    s = w.scene
+    keep = s.n_spheres
+    s.n_spheres = api.C.c_uint32(5000)
+    with pytest.raises(api.RtError) as e:
+        c.upload(s)
+    assert e.value.code == api.RT_ERR_SCENE_TOO_LARGE
+    s.n_spheres = keep
+    old = s.material_id[2]
+    s.material_id[2] = 77
+    with pytest.raises(api.RtError) as e:
+        c.upload(s)
+    assert e.value.code == api.RT_ERR_BAD_ARG and "material_id" in str(e.value)
+    s.material_id[2] = old
+    c.upload(s)
+    c.close()
+
+
+def test_device_accumulator_entry_point(ctx, api):
+    """rt_render_accum_device writes per-pixel SUMS into caller-owned device memory (the multi-GPU path)."""
+    import torch
+    w = api.World("Balls", seed=1, aspect=64 / 40)
+    ctx.upload(w.scene)
+    p = api.make_params(64, 40, 32, seed=3)
+    acc = torch.zeros(40, 64, 3, dtype=torch.float32, device="cuda:0")
+    torch.cuda.synchronize()
+    st = ctx.render_accum_device(w.camera, p, acc.data_ptr())
+    mean, _ = ctx.render(w.camera, p)
+    assert st.samples == 64 * 40 * 32
+    assert np.abs(acc.cpu().numpy() / 32 - mean).max() < 1e-6
