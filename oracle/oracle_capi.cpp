@@ -13,7 +13,7 @@ typedef struct orc_hit {
     double t;
     double point[3];
     double normal[3];
-    double margin;  // smallest relative distance of any decision from flipping (see below)
+    double margin;  // >= 1: every hit/miss/id decision is safely away from flipping in fp32 (see below)
 } orc_hit;
 
 typedef struct orc_scatter {
@@ -93,38 +93,50 @@ void orc_pcg_unit_disk(uint64_t seed, uint32_t n, double* out3) {
 
 }  // extern "C"
 
-// Decision margin of one ray (f64): the smallest of
-//   (a) |r^2 - l^2| / r^2 over all spheres (l = distance of the line from the centre): grazing,
-//   (b) |t_root / t_min - 1| over all real roots: a root sitting on the t_min boundary,
-//   (c) (t_2nd - t_best) * |d| / max(t_best * |d|, r_best): closest vs runner-up.
-// A ray whose margin is below the test's epsilon can legitimately flip hit/miss or
-// sphere id between f64 and fp32 arithmetic and is excluded from bit-exact checks.
+// Decision margin of one ray (f64), in units of "how far an fp32 evaluation is from flipping a decision";
+// >= 1 means every decision below is safe, < 1 means fp32 and f64 may legitimately disagree on hit/miss
+// or sphere id and the ray is excluded from bit-exact checks (and counted).  The smallest of
+//   (a) |disc/a| / max(|oc|^2, r^2) / (16 * 2^-24): the discriminant b^2 - a*c is a difference of two numbers
+//       of size |oc|^2; 16 fp32 ulps of that cancellation is the band in which its sign is not trustworthy.
+//       Only spheres that could change the answer count: not wholly behind t_min, not wholly beyond the
+//       closest hit.  (The r = 1000 ground is tested in f64 on the GPU, but it is held to the same rule.)
+//   (b) |t_root / t_min - 1| / 0.05 over the real roots of those spheres: a root sitting on the t_min boundary,
+//   (c) (t_2nd - t_best) * |d| / max(t_best * |d|, r_best) / 1e-3: closest vs runner-up near-tie.
 static double decision_margin(const Scene<double>& sc, const Ray<double>& ray, double t_min) {
-    double a = ray.dir.norm_squared(), len = std::sqrt(a);
-    double m = std::numeric_limits<double>::infinity();
-    double best = m, second = m, best_r = 1;
+    const double kDisc = 16.0 / 16777216.0, kTmin = 0.05, kTie = 1e-3;
+    const double a = ray.dir.norm_squared(), len = std::sqrt(a);
+    const double inf = std::numeric_limits<double>::infinity();
+    double best = inf, second = inf, best_r = 1;
+    struct Q { double hb, disc, r, oc2; };
+    std::vector<Q> q(sc.spheres.size());
     for (size_t i = 0; i < sc.spheres.size(); ++i) {
         const auto& s = sc.spheres[i];
         Vec3<double> oc = ray.origin - s.center(ray.time);
         double hb = oc.dot(ray.dir), c = oc.norm_squared() - s.radius * s.radius;
-        double disc = hb * hb - a * c;
-        double r2 = s.radius * s.radius;
-        m = std::min(m, std::fabs(disc / a) / r2);
-        if (disc >= 0) {
-            double root = std::sqrt(disc);
+        q[i] = {hb, hb * hb - a * c, s.radius, oc.norm_squared()};
+        if (q[i].disc >= 0) {
+            double root = std::sqrt(q[i].disc);
             double ts[2] = {(-hb - root) / a, (-hb + root) / a};
             double tv = -1;
-            for (double t : ts) {
-                m = std::min(m, std::fabs(t / t_min - 1.0));
+            for (double t : ts)
                 if (tv < 0 && t >= t_min) tv = t;
-            }
             if (tv >= 0) {
                 if (tv < best) { second = best; best = tv; best_r = s.radius; }
                 else if (tv < second) second = tv;
             }
         }
     }
-    if (std::isfinite(second)) m = std::min(m, (second - best) * len / std::max(best * len, best_r));
+    double m = inf;
+    for (const Q& s : q) {
+        const double tc = -s.hb / a, ext = 1.5 * s.r / len;  // closest approach +- a generous sphere extent
+        if (tc + ext < t_min || tc - ext > best) continue;   // cannot produce a hit in [t_min, best]
+        m = std::min(m, std::fabs(s.disc / a) / std::max(s.oc2, s.r * s.r) / kDisc);
+        if (s.disc >= 0) {
+            double root = std::sqrt(s.disc);
+            for (double t : {(-s.hb - root) / a, (-s.hb + root) / a}) m = std::min(m, std::fabs(t / t_min - 1.0) / kTmin);
+        }
+    }
+    if (std::isfinite(second)) m = std::min(m, (second - best) * len / std::max(best * len, best_r) / kTie);
     return m;
 }
 

@@ -120,6 +120,13 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64. Two HIP runtimes in one process
+    # cannot both own the GPU ("No HIP GPUs are available" in whichever initialises second), so when torch is
+    # installed let it load its runtime FIRST: our DT_NEEDED libamdhip64.so.7 then binds to that same copy.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(
             f"{LIB_PATH} not found: build it with `make -C raytracing_amd/csrc` "

@@ -86,7 +86,7 @@ def ray_cases(world, rng, n_primary, with_time):
     fwd = to_c / dist
     perp = np.cross(fwd, rng.normal(size=(k, 3)))
     perp /= np.linalg.norm(perp, axis=1, keepdims=True)
-    delta = rng.choice([-1e-2, -1e-3, -1e-4, 1e-4, 1e-3, 1e-2], k)[:, None]
+    delta = rng.choice([-3e-2, -1e-2, -4e-3, 4e-3, 1e-2, 3e-2], k)[:, None]
     target = c + perp * a["radius"][ids][:, None] * (1 + delta)
     graz = make_rays(o, (target - o) * rng.uniform(0.3, 2.0, (k, 1)))
     # inside spheres: origins strictly inside random spheres (far root, back face)

@@ -32,13 +32,13 @@ def rel_err(a, b, floor=1e-30):
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
 
 
-def check_hits(got, exp, eps_margin, tol=1e-5):
+def check_hits(got, exp, eps_margin, tol=1e-5, max_excluded=0.12):
     """north_star check (1): hit/miss, sphere id, material id and front_face BIT-EXACT for every ray whose
     f64 decision margin exceeds eps_margin; t and normal within `tol` relative. Returns stats dict."""
-    ok = exp["margin"] > eps_margin
+    ok = exp["margin"] >= eps_margin
     n = len(exp)
     stats = {"n": n, "excluded": int((~ok).sum())}
-    assert stats["excluded"] <= 0.12 * n, f"too many rays excluded by the margin: {stats}"
+    assert stats["excluded"] <= max_excluded * n, f"too many rays excluded by the margin: {stats}"
     for k in ("hit", "sphere_id", "material_id", "front_face"):
         bad = np.nonzero(ok & (got[k] != exp[k]))[0]
         assert len(bad) == 0, f"{k} differs on {len(bad)} of {ok.sum()} rays, first {bad[:5]}: got {got[k][bad[:5]]} exp {exp[k][bad[:5]]} margin {exp['margin'][bad[:5]]}"

@@ -16,7 +16,11 @@ from helpers import check_hits, rel_err, scene_checksum
 
 pytestmark = pytest.mark.gpu
 
-EPS_MARGIN = 1e-3  # relative decision margin below which a ray is excluded from the bit-exact checks
+# Rays whose decision margin (oracle_capi.cpp::decision_margin, in units of "16 fp32 ulps of the cancelled
+# discriminant / 5 % of t_min / 1e-3 relative near-tie") is below 1 are excluded from the bit-exact checks: any
+# fp32 sphere quadratic cancels b^2 against |oc|^2, so inside that band fp32 and f64 may disagree on hit/miss;
+# outside it they must not. Excluded counts are printed per case (0.1-0.2 % of generic rays).
+EPS_MARGIN = 1.0
 TOL = 1e-5         # north_star: t, normal, scatter direction within 1e-5 relative
 
 
@@ -49,7 +53,8 @@ def test_intersect_batches(ctx, api, name, case):
     assert scene_checksum(api, w) == str(g["checksum"])
     ctx.upload(w.scene)
     got = ctx.intersect_batch(g[f"{case}_rays"], 1e-3)
-    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL)
+    # the grazing set aims within r*(1 +- 4e-3..3e-2) of a limb on purpose: part of it lands inside the band
+    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL, max_excluded=0.10 if case == "grazing" else 0.01)
     print(name, case, stats)
     miss = got["hit"] == 0
     assert not got["t"][miss].any() and not got["normal"][miss].any()  # a miss is all zeros
@@ -60,8 +65,9 @@ def test_intersect_edge_cases(ctx, api, orc):
     ctx.upload(w.scene)
     assert len(ctx.intersect_batch(np.zeros(0, api.ray_dtype))) == 0  # empty batch
     r = np.zeros(5, api.ray_dtype)
-    r["origin"] = [[0, 0, 1], [0, 0, -0.5], [0, 0, -1], [0, 5, -1], [0, -0.4999, -1]]
-    r["dir"] = [[0, 0, 1], [0, 0, 1], [0, 0, 7], [0, -2, 0], [0, -1e-3, 0]]
+    # looks away / leaves from the surface / from the centre (far root) / from above / tiny direction from inside
+    r["origin"] = [[0, 0, 1], [0, 0, -0.5], [0, 0, -1], [0, 5, -1], [0, 0.4999, -1]]
+    r["dir"] = [[0, 0, 1], [0, 0, 1], [0, 0, 7], [0, -2, 0], [0, 1e-3, 0]]
     got = ctx.intersect_batch(r)
     exp = orc.intersect_batch(w.scene, r)
     assert got["hit"].tolist() == exp["hit"].tolist() == [0, 0, 1, 1, 1]

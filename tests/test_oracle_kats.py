@@ -127,7 +127,8 @@ def test_intersect_golden_and_bvh_agree(api, orc, name):
         assert np.array_equal(bvh["sphere_id"], exp["sphere_id"]) and np.array_equal(bvh["t"], exp["t"])
     # the cases do what they are meant to
     assert (g["inside_hits"]["front_face"] == 0).sum() > 0.6 * len(g["inside_hits"])
-    assert (g["grazing_hits"]["margin"] < 2.5e-2).mean() > 0.5  # aimed within r*(1 +- 1e-2) of a limb
+    # aimed within r*(1 +- 3e-2) of a limb: far tighter margins than generic primary rays
+    assert np.median(g["grazing_hits"]["margin"]) < 0.2 * np.median(g["primary_hits"]["margin"])
 
 
 def test_intersect_edge_cases(api, orc):

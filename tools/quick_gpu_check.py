@@ -29,7 +29,7 @@ def main():
     t0 = time.time()
     hg = ctx.intersect_batch(rays)
     ho = orc.intersect_batch(w.scene, rays)
-    ok = ho["margin"] > 1e-4
+    ok = ho["margin"] >= 1.0
     print("primary: n", n, "excluded", (~ok).sum(), "hit mismatch", (hg["hit"][ok] != ho["hit"][ok]).sum(),
           "id mismatch", (hg["sphere_id"][ok] != ho["sphere_id"][ok]).sum())
     both = ok & (hg["hit"] == 1) & (ho["hit"] == 1) & (hg["sphere_id"] == ho["sphere_id"])
@@ -47,7 +47,7 @@ def main():
     rays2["dir"] = sg["dir"][m]
     hg2 = ctx.intersect_batch(rays2)
     ho2 = orc.intersect_batch(w.scene, rays2)
-    ok2 = ho2["margin"] > 1e-4
+    ok2 = ho2["margin"] >= 1.0
     print("secondary: n", len(rays2), "excluded", (~ok2).sum(), "hit mismatch",
           (hg2["hit"][ok2] != ho2["hit"][ok2]).sum(), "id mismatch",
           (hg2["sphere_id"][ok2] != ho2["sphere_id"][ok2]).sum(), "hits", hg2["hit"].sum())
