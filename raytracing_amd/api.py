@@ -17,7 +17,7 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtx_hip.so")
+LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "librtx_hip.so")  # env override: A/B builds
 
 RT_OK = 0
 RT_ERR_BAD_ARG = -1

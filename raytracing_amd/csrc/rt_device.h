@@ -33,9 +33,9 @@ struct DevTexture {
 
 // Device view of an uploaded scene.
 struct DevScene {
-    // fp32 scan lists (global copies; each workgroup stages them into LDS)
-    const float4* stat;   // ns_pad x {cx, cy, cz, r^2}; pads have r^2 = -1 (never hit)
-    const float4* mov_a;  // nm_pad x {c0x, c0y, c0z, r^2}
+    // fp32 scan lists (read with scalar loads: wave-uniform index)
+    const float4* stat;   // ns_pad x {cx, cy, cz, -r^2}; pads have -r^2 = +1 at c = 0 (never hit)
+    const float4* mov_a;  // nm_pad x {c0x, c0y, c0z, -r^2}
     const float4* mov_b;  // nm_pad x {dcx, dcy, dcz, 0}
     const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
     int32_t ns_pad, nm_pad;
@@ -53,30 +53,21 @@ struct DevScene {
     int32_t n_textures;
 };
 
-// LDS image of the scene: [stat | mov_a | mov_b | tables]
+// LDS image: only the noise tables (gathered per lane, 24 dependent lookups per noise call).  The sphere
+// lists are NOT staged in LDS: they are wave-uniform and go through the scalar cache into SGPRs (see the scan).
 struct LdsScene {
-    const float4* stat;
-    const float4* mov_a;
-    const float4* mov_b;
     const rt_noise_table* tables;
 };
 
-__host__ __device__ inline size_t lds_scene_bytes(int ns_pad, int nm_pad, int n_tables) {
-    return (size_t)ns_pad * 16 + (size_t)nm_pad * 32 + (size_t)n_tables * sizeof(rt_noise_table);
-}
+__host__ __device__ inline size_t lds_scene_bytes(int n_tables) { return (size_t)n_tables * sizeof(rt_noise_table); }
 
 __device__ inline LdsScene stage_scene(const DevScene& S, unsigned char* lds, int tid, int nthreads) {
-    float4* stat = reinterpret_cast<float4*>(lds);
-    float4* mov_a = stat + S.ns_pad;
-    float4* mov_b = mov_a + S.nm_pad;
-    uint4* tab = reinterpret_cast<uint4*>(mov_b + S.nm_pad);
-    for (int i = tid; i < S.ns_pad; i += nthreads) stat[i] = S.stat[i];
-    for (int i = tid; i < S.nm_pad; i += nthreads) { mov_a[i] = S.mov_a[i]; mov_b[i] = S.mov_b[i]; }
+    uint4* tab = reinterpret_cast<uint4*>(lds);
     const uint4* gt = reinterpret_cast<const uint4*>(S.tables);
     const int nt = S.n_tables * (int)(sizeof(rt_noise_table) / 16);
     for (int i = tid; i < nt; i += nthreads) tab[i] = gt[i];
     __syncthreads();
-    return {stat, mov_a, mov_b, reinterpret_cast<const rt_noise_table*>(tab)};
+    return {reinterpret_cast<const rt_noise_table*>(tab)};
 }
 
 // ------------------------------------------------------------------ counter RNG
@@ -144,81 +135,129 @@ __device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
 }
 
 // ------------------------------------------------------------------ the fp32 sphere scan
-// One sphere against one ray, in a frame where the ray starts at o' = o + t_min*d and has a
-// UNIT direction.  Returns the bits of t' = (t - t_min)*|d| for the root the reference would
-// take, or a pattern that loses every unsigned min (negative -> sign bit set, miss -> NaN):
-//   nq = r^2 - |c - o'|^2  (> 0: o' inside the sphere)     b = (c - o').d      disc = b^2 + nq
-//   roots t' = b -+ sqrt(disc); their product is -nq, so exactly one root is positive when
-//   o' is inside (take b + s) and both have the sign of b when outside (take b - s): this is
-//   shape.rs:53-61's "near root if in range else far root" with the range start folded into o'.
-// 10 FMA-class ops + v_sqrt + v_bfi + v_add per sphere; the scan keeps only min(t') (v_min3_u32
-// takes two spheres per instruction) and, per chunk of 8, which chunk last lowered it.
-__device__ __forceinline__ uint32_t sphere_key(float cx, float cy, float cz, float r2, float ox, float oy,
-                                               float oz, float dx, float dy, float dz) {
-    const float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
-    const float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-    const float nq = fmaf(-ocz, ocz, fmaf(-ocy, ocy, fmaf(-ocx, ocx, r2)));
-    const float disc = fmaf(b, b, nq);
-    const float s = __builtin_amdgcn_sqrtf(disc);  // raw v_sqrt_f32: NaN for disc < 0
-    const float t = b + __builtin_copysignf(s, nq);
-    return __float_as_uint(t);
-}
-
+// One sphere against a ray, in a frame where the ray starts at o' = o + t_min*d and has a UNIT direction d^.
+// The key is the bit pattern of t' = (t - t_min)*|d| for the root the reference would take, or a pattern
+// that loses every unsigned min (negative -> sign bit set, miss -> NaN):
+//   oc = c - o'     b = oc.d^     q = |oc|^2 - r^2  (< 0: o' inside the sphere)     disc = b^2 - q
+//   roots t' = b -+ sqrt(disc); their product is q, so exactly one root is positive when o' is inside
+//   (take b + s) and both have the sign of b when outside (take b - s): this is shape.rs:53-61's
+//   "near root if in range else far root" with the range start folded into o'.
+//
+// How it is mapped to gfx950 (measured, tools/ubench*.hip):
+//  * A wave64 VALU instruction costs ~3.5-4 issue cycles whether or not its operands are SGPRs, and
+//    v_pk_{add,mul,fma}_f32 cost the same as their scalar forms while doing two lanes' worth: the 157 TF fp32
+//    peak exists only for packed math.  So EVERY LANE CARRIES TWO RAYS (A and B) and the ten
+//    arithmetic ops of a test are packed {A,B}: 53 -> 28 cycles per ray-test in the loop microbenchmark.
+//  * The sphere is wave-uniform: it is fetched with SCALAR loads (s_load_dwordx16 = 4 spheres, constant
+//    address space, served by the scalar cache) and used straight from SGPRs, so the loop has no LDS or
+//    vector-memory instruction and holds no sphere in VGPRs.
+//  * f32 MFMA does not help: v_mfma_f32_32x32x2_f32 and VALU fp32 do NOT overlap on this part (65 + 38 cycles
+//    measured 106 together), they share the fp32 datapath.
+//  * v_sqrt_f32 (~8-10 cycles), v_bfi (copysign) and the final subtract are the un-packable tail.
+// The scan keeps only min(t') per ray (v_min3_u32: two spheres per instruction) and, per chunk of 8, which
+// chunk last lowered it; the sphere id is recovered once per bounce by re-testing that chunk.
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef float f2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(4))) v4f* cv4p;  // constant address space => scalar loads
+__device__ __forceinline__ cv4p as_scalar(const float4* p) { return (cv4p)(uintptr_t)p; }
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 __device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
 
-// Scan both LDS lists.  `best` enters as the bound from the big-sphere test (or +inf bits).
-// On return `slot` is the chunk base (static: [0, ns_pad), moving: ns_pad + [0, nm_pad)) of the
-// chunk that produced the final minimum, or -1 when no small sphere beat the incoming bound.
-__device__ __forceinline__ void scan_spheres(const LdsScene& L, int ns_pad, int nm_pad, float ox, float oy,
-                                             float oz, float dx, float dy, float dz, float time,
-                                             uint32_t& best, int& slot) {
-    for (int base = 0; base < ns_pad; base += kChunk) {
-        const uint32_t prev = best;
+// the two rays of a lane, in the scan frame (component-wise pairs {A, B})
+struct Pair {
+    f2 ox, oy, oz;  // o' = o + t_min*d
+    f2 dx, dy, dz;  // unit direction
+    f2 time;
+};
+
+__device__ __forceinline__ void keys_finish(f2 b, f2 q, uint32_t& ka, uint32_t& kb) {
+    const f2 disc = fma2(b, b, -q);
+    const float sa = __builtin_amdgcn_sqrtf(disc.x), sb = __builtin_amdgcn_sqrtf(disc.y);  // NaN for disc < 0
+    const f2 sx = {__builtin_copysignf(sa, q.x), __builtin_copysignf(sb, q.y)};
+    const f2 t = b - sx;
+    ka = __float_as_uint(t.x);
+    kb = __float_as_uint(t.y);
+}
+// static sphere s = {cx, cy, cz, -r^2}
+__device__ __forceinline__ void keys_static(v4f s, const Pair& r, uint32_t& ka, uint32_t& kb) {
+    const f2 ocx = s.x - r.ox, ocy = s.y - r.oy, ocz = s.z - r.oz;
+    const f2 b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
+    const f2 q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{s.w, s.w})));
+    keys_finish(b, q, ka, kb);
+}
+// moving sphere a = {c0, -r^2}, m = {dc, 0}: center(time) = c0 + time*dc (shape.rs:96-98)
+__device__ __forceinline__ void keys_moving(v4f a, v4f m, const Pair& r, uint32_t& ka, uint32_t& kb) {
+    const f2 ocx = fma2(r.time, f2{m.x, m.x}, a.x - r.ox), ocy = fma2(r.time, f2{m.y, m.y}, a.y - r.oy),
+             ocz = fma2(r.time, f2{m.z, m.z}, a.z - r.oz);
+    const f2 b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
+    const f2 q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
+    keys_finish(b, q, ka, kb);
+}
+
+// Scan both lists for both rays.  best[] enter as the bounds from the big-sphere test (or +inf bits).  On
+// return slot[i] is the chunk base (static: [0, ns_pad), moving: ns_pad + [0, nm_pad)) of the chunk that
+// produced ray i's final minimum, or stays -1 when no small sphere beat the incoming bound.
+__device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, uint32_t& best_a, uint32_t& best_b,
+                                             int& slot_a, int& slot_b) {
+    const cv4p st = as_scalar(S.stat);
+    for (int base = 0; base < S.ns_pad; base += kChunk) {
+        const uint32_t pa = best_a, pb = best_b;
 #pragma unroll
         for (int k = 0; k < kChunk; k += 2) {
-            const float4 a = L.stat[base + k], c = L.stat[base + k + 1];
-            const uint32_t ka = sphere_key(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
-            const uint32_t kc = sphere_key(c.x, c.y, c.z, c.w, ox, oy, oz, dx, dy, dz);
-            best = umin3(best, ka, kc);
+            uint32_t a0, b0, a1, b1;
+            keys_static(st[base + k], r, a0, b0);
+            keys_static(st[base + k + 1], r, a1, b1);
+            best_a = umin3(best_a, a0, a1);
+            best_b = umin3(best_b, b0, b1);
         }
-        slot = (best != prev) ? base : slot;
+        slot_a = (best_a != pa) ? base : slot_a;
+        slot_b = (best_b != pb) ? base : slot_b;
     }
-    for (int base = 0; base < nm_pad; base += kChunk) {
-        const uint32_t prev = best;
+    const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
+    for (int base = 0; base < S.nm_pad; base += kChunk) {
+        const uint32_t pa = best_a, pb = best_b;
 #pragma unroll
         for (int k = 0; k < kChunk; k += 2) {
-            const float4 a = L.mov_a[base + k], ad = L.mov_b[base + k];
-            const float4 c = L.mov_a[base + k + 1], cd = L.mov_b[base + k + 1];
-            // center(time) = c0 + time*dc (shape.rs:96-98)
-            const uint32_t ka = sphere_key(fmaf(time, ad.x, a.x), fmaf(time, ad.y, a.y), fmaf(time, ad.z, a.z),
-                                           a.w, ox, oy, oz, dx, dy, dz);
-            const uint32_t kc = sphere_key(fmaf(time, cd.x, c.x), fmaf(time, cd.y, c.y), fmaf(time, cd.z, c.z),
-                                           c.w, ox, oy, oz, dx, dy, dz);
-            best = umin3(best, ka, kc);
+            uint32_t a0, b0, a1, b1;
+            keys_moving(ma[base + k], mb[base + k], r, a0, b0);
+            keys_moving(ma[base + k + 1], mb[base + k + 1], r, a1, b1);
+            best_a = umin3(best_a, a0, a1);
+            best_b = umin3(best_b, b0, b1);
         }
-        slot = (best != prev) ? ns_pad + base : slot;
+        slot_a = (best_a != pa) ? S.ns_pad + base : slot_a;
+        slot_b = (best_b != pb) ? S.ns_pad + base : slot_b;
     }
 }
 
-// Which of the 8 spheres of chunk `slot` is the closest: per-lane LDS gather, once per bounce.
-__device__ __forceinline__ int resolve_slot(const LdsScene& L, int ns_pad, int slot, float ox, float oy, float oz,
-                                            float dx, float dy, float dz, float time) {
+// Which of the 8 spheres of chunk `slot` is the closest for ONE ray: per-lane gather (L1/L2), once per
+// bounce.  Same arithmetic as the scan, unpacked.
+__device__ __forceinline__ uint32_t key_one(float cx, float cy, float cz, float w, float ox, float oy, float oz,
+                                            float dx, float dy, float dz) {
+    const float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
+    const float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
+    const float q = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, w)));
+    const float disc = fmaf(b, b, -q);
+    const float s = __builtin_amdgcn_sqrtf(disc);
+    return __float_as_uint(b - __builtin_copysignf(s, q));
+}
+__device__ __forceinline__ int resolve_slot(const DevScene& S, int slot, float ox, float oy, float oz, float dx,
+                                            float dy, float dz, float time) {
     uint32_t best = 0xFFFFFFFFu;
     int idx = slot;
-    if (slot < ns_pad) {
+    if (slot < S.ns_pad) {
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
-            const float4 a = L.stat[slot + k];
-            const uint32_t key = sphere_key(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
+            const float4 a = S.stat[slot + k];
+            const uint32_t key = key_one(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
             if (key < best) { best = key; idx = slot + k; }
         }
     } else {
-        const int m = slot - ns_pad;
+        const int m = slot - S.ns_pad;
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
-            const float4 a = L.mov_a[m + k], ad = L.mov_b[m + k];
-            const uint32_t key = sphere_key(fmaf(time, ad.x, a.x), fmaf(time, ad.y, a.y), fmaf(time, ad.z, a.z),
-                                            a.w, ox, oy, oz, dx, dy, dz);
+            const float4 a = S.mov_a[m + k], d = S.mov_b[m + k];
+            const uint32_t key = key_one(fmaf(time, d.x, a.x), fmaf(time, d.y, a.y), fmaf(time, d.z, a.z), a.w, ox,
+                                         oy, oz, dx, dy, dz);
             if (key < best) { best = key; idx = slot + k; }
         }
     }
@@ -257,63 +296,89 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     return true;
 }
 
-// HitList::hit(ray, t_min..inf) (hit.rs:100-110): closest hit over the whole world.
-__device__ __forceinline__ HitRec closest_hit(const DevScene& S, const LdsScene& L, const Ray& r, float t_min) {
+// Per-ray state around the packed scan: the f64 big-sphere pass before it and the f64 hit record after it.
+struct HitWork {
+    double t_best, c_best[3];
+    int id_best;
+    float inv_len, len;
+};
+__device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, float t_min, HitWork& w) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    double t_best = inf, c_best[3] = {0, 0, 0};
-    int id_best = -1;
-    // (1) big spheres, f64, world order
-    for (int k = 0; k < S.n_big; ++k) {
+    w.t_best = inf;
+    w.c_best[0] = w.c_best[1] = w.c_best[2] = 0.0;
+    w.id_best = -1;
+    for (int k = 0; k < S.n_big; ++k) {  // big spheres, f64, world order
         double t, c[3];
         const int id = S.big_id[k];
-        if (sphere_hit_f64(S, id, r, (double)t_min, t_best, false, t, c)) {
-            t_best = t; id_best = id;
-            c_best[0] = c[0]; c_best[1] = c[1]; c_best[2] = c[2];
+        if (sphere_hit_f64(S, id, r, (double)t_min, w.t_best, false, t, c)) {
+            w.t_best = t; w.id_best = id;
+            w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
     }
-    // (2) fp32 scan of the LDS lists in the shifted, unit-direction frame
     const float len2 = dot(r.d, r.d);
-    const float inv_len = 1.0f / sqrtf(len2);
-    const float len = len2 * inv_len;
-    const float dx = r.d.x * inv_len, dy = r.d.y * inv_len, dz = r.d.z * inv_len;
-    const float ox = fmaf(t_min, r.d.x, r.o.x), oy = fmaf(t_min, r.d.y, r.o.y), oz = fmaf(t_min, r.d.z, r.o.z);
-    uint32_t bound = kInfBits;
-    if (id_best >= 0) {
-        const float tb = (float)((t_best - (double)t_min) * (double)len);
-        bound = __float_as_uint(fmaxf(tb, 0.0f));
-    }
-    uint32_t best = bound;
-    int slot = -1;
-    scan_spheres(L, S.ns_pad, S.nm_pad, ox, oy, oz, dx, dy, dz, r.time, best, slot);
-    // (3) the winner of the scan, re-derived in f64 for the hit record
-    if (slot >= 0 && best < kInfBits) {
-        const int idx = resolve_slot(L, S.ns_pad, slot, ox, oy, oz, dx, dy, dz, r.time);
+    w.inv_len = 1.0f / sqrtf(len2);
+    w.len = len2 * w.inv_len;
+    if (w.id_best < 0) return kInfBits;
+    const float tb = (float)((w.t_best - (double)t_min) * (double)w.len);
+    return __float_as_uint(fmaxf(tb, 0.0f));
+}
+__device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float t_min, HitWork& w, uint32_t best,
+                                          int slot, float ox, float oy, float oz, float dx, float dy, float dz) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    if (slot >= 0 && best < kInfBits) {  // the scan's winner, re-derived in f64 for the hit record
+        const int idx = resolve_slot(S, slot, ox, oy, oz, dx, dy, dz, r.time);
         const int id = S.scan_id[idx];
         double t, c[3];
-        if (sphere_hit_f64(S, id, r, (double)t_min, inf, true, t, c) && t < t_best) {
-            t_best = t; id_best = id;
-            c_best[0] = c[0]; c_best[1] = c[1]; c_best[2] = c[2];
+        if (id >= 0 && sphere_hit_f64(S, id, r, (double)t_min, inf, true, t, c) && t < w.t_best) {
+            w.t_best = t; w.id_best = id;
+            w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
     }
     HitRec h;
-    h.sphere = id_best;
-    if (id_best < 0) {
+    h.sphere = w.id_best;
+    if (w.id_best < 0) {
         h.front = 0; h.t = 0.0f; h.p = {0, 0, 0}; h.n = {0, 0, 0};
         return h;
     }
     // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
-    const double px = (double)r.o.x + t_best * (double)r.d.x;
-    const double py = (double)r.o.y + t_best * (double)r.d.y;
-    const double pz = (double)r.o.z + t_best * (double)r.d.z;
-    const double rad = (double)S.rad[id_best];
-    double nx = (px - c_best[0]) / rad, ny = (py - c_best[1]) / rad, nz = (pz - c_best[2]) / rad;
+    const double px = (double)r.o.x + w.t_best * (double)r.d.x;
+    const double py = (double)r.o.y + w.t_best * (double)r.d.y;
+    const double pz = (double)r.o.z + w.t_best * (double)r.d.z;
+    const double rad = (double)S.rad[w.id_best];
+    double nx = (px - w.c_best[0]) / rad, ny = (py - w.c_best[1]) / rad, nz = (pz - w.c_best[2]) / rad;
     const bool front = ((double)r.d.x * nx + (double)r.d.y * ny + (double)r.d.z * nz) < 0.0;
     if (!front) { nx = -nx; ny = -ny; nz = -nz; }
     h.front = front ? 1 : 0;
-    h.t = (float)t_best;
+    h.t = (float)w.t_best;
     h.p = {(float)px, (float)py, (float)pz};
     h.n = {(float)nx, (float)ny, (float)nz};
     return h;
+}
+
+// HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world.
+// do_a / do_b: whether that ray is live (a dead one still rides through the packed scan, its result is dropped).
+__device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                             float t_min, HitRec& ha, HitRec& hb) {
+    HitWork wa, wb;
+    uint32_t best_a = kInfBits, best_b = kInfBits;
+    wa.id_best = wb.id_best = -1;
+    wa.inv_len = wb.inv_len = 1.0f;
+    if (do_a) best_a = hit_begin(S, ra, t_min, wa);
+    if (do_b) best_b = hit_begin(S, rb, t_min, wb);
+    Pair p;
+    p.dx = f2{ra.d.x * wa.inv_len, rb.d.x * wb.inv_len};
+    p.dy = f2{ra.d.y * wa.inv_len, rb.d.y * wb.inv_len};
+    p.dz = f2{ra.d.z * wa.inv_len, rb.d.z * wb.inv_len};
+    p.ox = f2{fmaf(t_min, ra.d.x, ra.o.x), fmaf(t_min, rb.d.x, rb.o.x)};
+    p.oy = f2{fmaf(t_min, ra.d.y, ra.o.y), fmaf(t_min, rb.d.y, rb.o.y)};
+    p.oz = f2{fmaf(t_min, ra.d.z, ra.o.z), fmaf(t_min, rb.d.z, rb.o.z)};
+    p.time = f2{ra.time, rb.time};
+    int slot_a = -1, slot_b = -1;
+    scan_spheres(S, p, best_a, best_b, slot_a, slot_b);
+    ha.sphere = -1;
+    hb.sphere = -1;
+    if (do_a) ha = hit_end(S, ra, t_min, wa, best_a, slot_a, p.ox.x, p.oy.x, p.oz.x, p.dx.x, p.dy.x, p.dz.x);
+    if (do_b) hb = hit_end(S, rb, t_min, wb, best_b, slot_b, p.ox.y, p.oy.y, p.oz.y, p.dx.y, p.dy.y, p.dz.y);
 }
 
 // ------------------------------------------------------------------ textures

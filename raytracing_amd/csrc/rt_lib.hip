@@ -10,6 +10,9 @@
 #include <string>
 #include <vector>
 
+#ifndef RT_PREFETCH
+#define RT_PREFETCH 0
+#endif
 #include "rt_device.h"
 
 using namespace rtd;
@@ -38,13 +41,23 @@ struct RenderArgs {
     unsigned long long* rays;
 };
 
-// One wave = one 8x8 tile x one spp chunk.  The wave runs a private work queue of
-// (pixel, sample) items: a lane whose path ended takes the next item, so every lane has a live
-// ray in (almost) every pass of the sphere scan regardless of how path lengths differ.
-// Radiance is summed in 2^-32 fixed point (order-independent => bit-reproducible images
-// whatever the chunking, tiling or lane scheduling): LDS per wave, then one global atomic
-// per pixel-channel.
-__global__ __launch_bounds__(kBlock) void render_kernel(const RenderArgs A) {
+// One wave = one 8x8 tile x one spp chunk, and every lane carries TWO paths (the packed scan tests both
+// against each sphere in one instruction stream).  The wave runs a private work queue of (pixel, sample)
+// items: a path slot whose path ended takes the next item, so every slot has a live ray in (almost) every
+// pass of the sphere scan regardless of how path lengths differ.  Radiance is summed in 2^-32 fixed point
+// (order-independent => bit-reproducible images whatever the chunking, tiling or lane scheduling): LDS per
+// wave, then one global atomic per pixel-channel.
+struct PathState {
+    Ray ray;
+    f3 thr;
+    uint32_t pix_local, pix, smp, depth;
+    bool alive;
+};
+
+#ifndef RT_WAVES_PER_EU
+#define RT_WAVES_PER_EU 1
+#endif
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -67,72 +80,85 @@ __global__ __launch_bounds__(kBlock) void render_kernel(const RenderArgs A) {
     const float inv_w = 1.0f / ((float)A.W - 1.0f), inv_h = 1.0f / ((float)A.H - 1.0f);
 
     uint32_t next = 0;
-    bool alive = false;
-    Ray ray = {{0, 0, 0}, {0, 0, 1}, 0};
-    f3 thr = {1, 1, 1};
-    uint32_t pix_local = 0, pix = 0, smp = 0, depth = 0;
+    PathState ps[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        ps[s].ray = {{0, 0, 0}, {0, 0, 1}, 0};
+        ps[s].thr = {1, 1, 1};
+        ps[s].pix_local = ps[s].pix = ps[s].smp = ps[s].depth = 0;
+        ps[s].alive = false;
+    }
     unsigned long long n_rays = 0;
 
     for (;;) {
-        // ---- refill dead lanes from the wave's queue
-        const unsigned long long need = __ballot(!alive);
-        if (!alive) {
-            const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
-                                                                   __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
-            if (item < total) {
-                const uint32_t s = item / npix;
-                pix_local = item - s * npix;
-                const uint32_t ly = pix_local / tw, lx = pix_local - ly * tw;
-                const uint32_t x = tx0 + lx, y = ty0 + ly;
-                pix = y * A.W + x;
-                smp = A.spp_first + s_lo + s;
-                uint32_t r0[4];
-                philox4x32_10(A.k0, A.k1, pix, smp, DIM_PIXEL, 0u, r0);
-                const float ri = A.antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
-                const float rj = A.antialias ? u01(r0[1]) : 0.0f;
-                const float ci = ((float)x + ri) * inv_w;           // main.rs:81
-                const float cj = 1.0f - ((float)y + rj) * inv_h;    // main.rs:82
-                float ut = 0.0f;
-                if (A.cam.has_shutter) {
-                    uint32_t r1[4];
-                    philox4x32_10(A.k0, A.k1, pix, smp, DIM_TIME, 0u, r1);
-                    ut = u01(r1[0]);
-                }
-                ray = camera_ray(A.cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
-                thr = {1.0f, 1.0f, 1.0f};
-                depth = 0;
-                alive = true;
-            }
-        }
-        next += (uint32_t)__popcll(need);
-        if (__ballot(alive) == 0ull) break;
-
-        // ---- one ray segment per live lane: closest hit, then scatter or terminate
-        if (alive) {
-            ++n_rays;
-            const HitRec h = closest_hit(A.S, L, ray, A.t_min);
-            bool done = false;
-            f3 rad = {0, 0, 0};
-            if (h.sphere < 0) {  // main.rs:133-138
-                rad = thr * sky(ray.d);
-                done = true;
-            } else {
-                uint32_t rb[4];
-                philox4x32_10(A.k0, A.k1, pix, smp, DIM_BOUNCE0 + depth, 0u, rb);
-                const f3 albedo = scatter(A.S, L.tables, h, ray, u01(rb[0]), u01(rb[1]));
-                thr = thr * albedo;  // main.rs:118
-                ++depth;
-                if (depth == A.max_depth) done = true;  // main.rs:126-130: black
-            }
-            if (done) {
-                alive = false;
-                const float c[3] = {rad.x, rad.y, rad.z};
+        // ---- refill dead path slots from the wave's queue
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float v = c[k];
-                    v = (v > 0.0f) ? fminf(v, 1048576.0f) : 0.0f;  // NaN / negative -> 0
-                    const unsigned long long q = (unsigned long long)(v * kTwoPow32);
-                    if (q) atomicAdd(&acc[pix_local * 3 + k], q);
+        for (int s = 0; s < 2; ++s) {
+            PathState& P = ps[s];
+            const unsigned long long need = __ballot(!P.alive);
+            if (!P.alive) {
+                const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
+                                                                       __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
+                if (item < total) {
+                    const uint32_t smp_i = item / npix;
+                    P.pix_local = item - smp_i * npix;
+                    const uint32_t ly = P.pix_local / tw, lx = P.pix_local - ly * tw;
+                    const uint32_t x = tx0 + lx, y = ty0 + ly;
+                    P.pix = y * A.W + x;
+                    P.smp = A.spp_first + s_lo + smp_i;
+                    uint32_t r0[4];
+                    philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_PIXEL, 0u, r0);
+                    const float ri = A.antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
+                    const float rj = A.antialias ? u01(r0[1]) : 0.0f;
+                    const float ci = ((float)x + ri) * inv_w;           // main.rs:81
+                    const float cj = 1.0f - ((float)y + rj) * inv_h;    // main.rs:82
+                    float ut = 0.0f;
+                    if (A.cam.has_shutter) {
+                        uint32_t r1[4];
+                        philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_TIME, 0u, r1);
+                        ut = u01(r1[0]);
+                    }
+                    P.ray = camera_ray(A.cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
+                    P.thr = {1.0f, 1.0f, 1.0f};
+                    P.depth = 0;
+                    P.alive = true;
+                }
+            }
+            next += (uint32_t)__popcll(need);
+        }
+        if (__ballot(ps[0].alive || ps[1].alive) == 0ull) break;
+
+        // ---- one ray segment per live path: closest hit (both paths in one packed scan), then scatter
+        HitRec h[2];
+        closest_hit2(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, h[0], h[1]);
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            PathState& P = ps[s];
+            if (P.alive) {
+                ++n_rays;
+                bool done = false;
+                f3 rad = {0, 0, 0};
+                if (h[s].sphere < 0) {  // main.rs:133-138
+                    rad = P.thr * sky(P.ray.d);
+                    done = true;
+                } else {
+                    uint32_t rb[4];
+                    philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_BOUNCE0 + P.depth, 0u, rb);
+                    const f3 albedo = scatter(A.S, L.tables, h[s], P.ray, u01(rb[0]), u01(rb[1]));
+                    P.thr = P.thr * albedo;  // main.rs:118
+                    ++P.depth;
+                    if (P.depth == A.max_depth) done = true;  // main.rs:126-130: black
+                }
+                if (done) {
+                    P.alive = false;
+                    const float c[3] = {rad.x, rad.y, rad.z};
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) {
+                        float v = c[k];
+                        v = (v > 0.0f) ? fminf(v, 1048576.0f) : 0.0f;  // NaN / negative -> 0
+                        const unsigned long long q = (unsigned long long)(v * kTwoPow32);
+                        if (q) atomicAdd(&acc[P.pix_local * 3 + k], q);
+                    }
                 }
             }
         }
@@ -161,15 +187,7 @@ __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, fl
 }
 
 // ---- fixed-batch kernels (parity entry points) --------------------------------------------
-__global__ __launch_bounds__(kBlock) void intersect_batch_kernel(const DevScene S, const rt_ray* __restrict__ rays,
-                                                                 uint32_t n, float t_min, rt_hit* __restrict__ out) {
-    extern __shared__ __align__(16) unsigned char lds[];
-    const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const rt_ray q = rays[i];
-    Ray r = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time};
-    const HitRec h = closest_hit(S, L, r, t_min);
+__device__ inline void store_hit(const DevScene& S, const HitRec& h, rt_hit* out) {
     rt_hit o;
     memset(&o, 0, sizeof(o));
     if (h.sphere >= 0) {
@@ -181,7 +199,20 @@ __global__ __launch_bounds__(kBlock) void intersect_batch_kernel(const DevScene 
         o.point[0] = h.p.x; o.point[1] = h.p.y; o.point[2] = h.p.z;
         o.normal[0] = h.n.x; o.normal[1] = h.n.y; o.normal[2] = h.n.z;
     }
-    out[i] = o;
+    *out = o;
+}
+// thread i tests rays 2i and 2i+1: the same two-rays-per-lane closest_hit2 the render kernel uses
+__global__ __launch_bounds__(kBlock) void intersect_batch_kernel(const DevScene S, const rt_ray* __restrict__ rays,
+                                                                 uint32_t n, float t_min, rt_hit* __restrict__ out) {
+    const uint32_t i0 = 2 * (blockIdx.x * kBlock + threadIdx.x), i1 = i0 + 1;
+    const bool do_a = i0 < n, do_b = i1 < n;
+    Ray ra = {{0, 0, 0}, {0, 0, 1}, 0}, rb = ra;
+    if (do_a) { const rt_ray q = rays[i0]; ra = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time}; }
+    if (do_b) { const rt_ray q = rays[i1]; rb = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time}; }
+    HitRec ha, hb;
+    closest_hit2(S, ra, rb, do_a, do_b, t_min, ha, hb);
+    if (do_a) store_hit(S, ha, out + i0);
+    if (do_b) store_hit(S, hb, out + i1);
 }
 
 __global__ __launch_bounds__(kBlock) void scatter_batch_kernel(const DevScene S, const rt_ray* __restrict__ rays,
@@ -444,23 +475,24 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         if (r >= kBigRadius || cm >= kBigCenter) {
             big_id.push_back((int32_t)i);
         } else if (moving) {
-            mov_a.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], r * r));
+            mov_a.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], -(r * r)));
             mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
             mov_id.push_back((int32_t)i);
         } else {
-            stat.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], r * r));
+            stat.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], -(r * r)));
             stat_id.push_back((int32_t)i);
         }
     }
-    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, -1.0f)); stat_id.push_back(-1); }
+    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, 1.0f)); stat_id.push_back(-1); }
     while (mov_a.size() % kChunk) {
-        mov_a.push_back(make_float4(0, 0, 0, -1.0f));
+        mov_a.push_back(make_float4(0, 0, 0, 1.0f));
         mov_b.push_back(make_float4(0, 0, 0, 0));
         mov_id.push_back(-1);
     }
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
-    const size_t lds_need = lds_scene_bytes((int)stat.size(), (int)mov_a.size(), (int)s->n_noise_tables);
+    const size_t lds_need = lds_scene_bytes((int)s->n_noise_tables);
+    if ((stat.size() + 2 * mov_a.size()) * 16 > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "sphere lists exceed 64 KiB");
     if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
 
     free_scene(c);
@@ -547,6 +579,7 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         const uint32_t spp_l = std::min(spp_per_launch, p->spp - done);
         uint32_t chunks = (uint32_t)std::min<uint64_t>(spp_l, (target_waves + A.n_tiles - 1) / A.n_tiles);
         chunks = std::max(1u, std::min(chunks, 65535u));
+        if (p->reserved) chunks = std::max(1u, (spp_l + p->reserved - 1) / p->reserved);  // debug/test hook: force spp per chunk
         A.spp_first = p->spp_offset + done;
         A.spp_count = spp_l;
         A.spp_per_chunk = (spp_l + chunks - 1) / chunks;
@@ -608,7 +641,7 @@ int rt_intersect_batch(rt_ctx* c, const rt_ray* rays, uint32_t n, float t_min, r
     RT_TMP(c, dr, n * sizeof(rt_ray));
     RT_TMP(c, dh, n * sizeof(rt_hit));
     RT_HIP(c, hipMemcpy(dr.p, rays, n * sizeof(rt_ray), hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(intersect_batch_kernel, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), c->lds_scene, c->stream,
+    hipLaunchKernelGGL(intersect_batch_kernel, dim3((n + 2 * kBlock - 1) / (2 * kBlock)), dim3(kBlock), 0, c->stream,
                        c->S, (const rt_ray*)dr.p, n, t_min, (rt_hit*)dh.p);
     RT_HIP(c, hipGetLastError());
     RT_HIP(c, hipStreamSynchronize(c->stream));
