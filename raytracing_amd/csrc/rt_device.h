@@ -43,7 +43,7 @@ struct DevScene {
     const int32_t* big_id;
     int32_t n_big;
     // world-order SoA for the f64 hit record of the winning sphere
-    const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad;
+    const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad, *inv_rad;
     const uint32_t* mat_id;
     const rt_material* mats;
     const DevTexture* texs;
@@ -77,12 +77,12 @@ __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t
                                               uint32_t c3, uint32_t out[4]) {
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-        c0 = hi1 ^ c1 ^ k0;
-        c1 = lo1;
-        c2 = hi0 ^ c3 ^ k1;
-        c3 = lo0;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi + mul_lo pair
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        c1 = (uint32_t)p1;
+        c2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        c3 = (uint32_t)p0;
         k0 += 0x9E3779B9u;
         k1 += 0xBB67AE85u;
     }
@@ -102,9 +102,14 @@ __device__ __forceinline__ f3 operator-(f3 a, f3 b) { return {a.x - b.x, a.y - b
 __device__ __forceinline__ f3 operator*(f3 a, float s) { return {a.x * s, a.y * s, a.z * s}; }
 __device__ __forceinline__ f3 operator*(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
 __device__ __forceinline__ float dot(f3 a, f3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+// Shading uses the 1-ulp hardware v_rsq_f32 / v_rcp_f32 / v_sqrt_f32 (not the IEEE-correct multi-instruction
+// expansions): the parity bar for directions is 1e-5 relative, these are ~1e-7.
+__device__ __forceinline__ float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 __device__ __forceinline__ f3 normalize(f3 a) {
-    const float n = sqrtf(dot(a, a));
-    return {a.x / n, a.y / n, a.z / n};
+    const float inv = fast_rsq(dot(a, a));
+    return {a.x * inv, a.y * inv, a.z * inv};
 }
 
 struct Ray {
@@ -122,13 +127,13 @@ struct HitRec {
 // oracle; same distributions as rand_distr::UnitSphere / UnitDisc used at vec3.rs:53-62)
 __device__ __forceinline__ f3 map_unit_sphere(float u0, float u1) {
     const float z = 1.0f - 2.0f * u0;
-    const float r = sqrtf(fmaxf(0.0f, 1.0f - z * z));
+    const float r = fast_sqrt(fmaxf(0.0f, 1.0f - z * z));
     float s, c;
     sincospif(2.0f * u1, &s, &c);
     return {r * c, r * s, z};
 }
 __device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
-    const float r = sqrtf(u0);
+    const float r = fast_sqrt(u0);
     float s, c;
     sincospif(2.0f * u1, &s, &c);
     return {r * c, r * s, 0.0f};
@@ -268,8 +273,9 @@ __device__ __forceinline__ int resolve_slot(const DevScene& S, int slot, float o
 // shape.rs:35-65 / :101-133 verbatim in f64 on the fp32 inputs, unnormalised direction:
 // near root if t_min <= t < t_max else far root.  `clamp_disc`: the fp32 scan already decided
 // "hit", so a discriminant that f64 puts a hair below zero is a grazing hit, not a miss.
-__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double t_min, double t_max,
-                                               bool clamp_disc, double& t_out, double c_out[3]) {
+__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
+                                               double t_min, double t_max, bool clamp_disc, double& t_out,
+                                               double c_out[3]) {
     const double tm = (double)r.time;
     const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];
     const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
@@ -277,17 +283,16 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     const double rad = (double)S.rad[id];
     const double ocx = (double)r.o.x - cx, ocy = (double)r.o.y - cy, ocz = (double)r.o.z - cz;
     const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
-    const double a = dx * dx + dy * dy + dz * dz;
     const double hb = ocx * dx + ocy * dy + ocz * dz;
     const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
     double disc = hb * hb - a * c;
     if (clamp_disc) disc = fmax(disc, 0.0);
     if (!(disc >= 0.0)) return false;
     const double root = sqrt(disc);
-    double t = (-hb - root) / a;
+    double t = (-hb - root) * inv_a;  // one f64 reciprocal per ray instead of a division per root
     bool ok = (t >= t_min) && (t < t_max);
     if (!ok) {
-        t = (-hb + root) / a;
+        t = (-hb + root) * inv_a;
         ok = (t >= t_min) && (t < t_max);
     }
     if (!ok) return false;
@@ -301,22 +306,25 @@ struct HitWork {
     double t_best, c_best[3];
     int id_best;
     float inv_len, len;
+    double a, inv_a;  // |d|^2 and its reciprocal, f64
 };
 __device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, float t_min, HitWork& w) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     w.t_best = inf;
     w.c_best[0] = w.c_best[1] = w.c_best[2] = 0.0;
     w.id_best = -1;
+    w.a = (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
+    w.inv_a = 1.0 / w.a;
     for (int k = 0; k < S.n_big; ++k) {  // big spheres, f64, world order
         double t, c[3];
         const int id = S.big_id[k];
-        if (sphere_hit_f64(S, id, r, (double)t_min, w.t_best, false, t, c)) {
+        if (sphere_hit_f64(S, id, r, w.a, w.inv_a, (double)t_min, w.t_best, false, t, c)) {
             w.t_best = t; w.id_best = id;
             w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
     }
-    const float len2 = dot(r.d, r.d);
-    w.inv_len = 1.0f / sqrtf(len2);
+    const float len2 = (float)w.a;
+    w.inv_len = fast_rsq(len2);
     w.len = len2 * w.inv_len;
     if (w.id_best < 0) return kInfBits;
     const float tb = (float)((w.t_best - (double)t_min) * (double)w.len);
@@ -329,7 +337,7 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
         const int idx = resolve_slot(S, slot, ox, oy, oz, dx, dy, dz, r.time);
         const int id = S.scan_id[idx];
         double t, c[3];
-        if (id >= 0 && sphere_hit_f64(S, id, r, (double)t_min, inf, true, t, c) && t < w.t_best) {
+        if (id >= 0 && sphere_hit_f64(S, id, r, w.a, w.inv_a, (double)t_min, inf, true, t, c) && t < w.t_best) {
             w.t_best = t; w.id_best = id;
             w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
@@ -344,8 +352,8 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     const double px = (double)r.o.x + w.t_best * (double)r.d.x;
     const double py = (double)r.o.y + w.t_best * (double)r.d.y;
     const double pz = (double)r.o.z + w.t_best * (double)r.d.z;
-    const double rad = (double)S.rad[w.id_best];
-    double nx = (px - w.c_best[0]) / rad, ny = (py - w.c_best[1]) / rad, nz = (pz - w.c_best[2]) / rad;
+    const double ir = (double)S.inv_rad[w.id_best];  // 1/r rounded to fp32: |n| = 1 +- 6e-8
+    double nx = (px - w.c_best[0]) * ir, ny = (py - w.c_best[1]) * ir, nz = (pz - w.c_best[2]) * ir;
     const bool front = ((double)r.d.x * nx + (double)r.d.y * ny + (double)r.d.z * nz) < 0.0;
     if (!front) { nx = -nx; ny = -ny; nz = -nz; }
     h.front = front ? 1 : 0;
@@ -479,39 +487,44 @@ __device__ __forceinline__ f3 reflect_unit(f3 ud, f3 n) {  // vec3.rs:113-116 af
     return {ud.x - k * n.x, ud.y - k * n.y, ud.z - k * n.z};
 }
 __device__ __forceinline__ float schlick(float cosv, float eta) {  // material.rs:84-88
-    float r0 = (1.0f - eta) / (1.0f + eta);
+    float r0 = (1.0f - eta) * fast_rcp(1.0f + eta);
     r0 *= r0;
     const float m = 1.0f - cosv;
     return r0 + (1.0f - r0) * (m * m * m * m * m);
 }
 // Material::scatter with explicit uniforms u0,u1.  Returns the albedo; `r` becomes the scattered ray.
+// Lanes of a wave hold different materials, so the three branches usually all run: what they share (the unit
+// incident direction, the unit-sphere sample) is computed once outside them.
 __device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables, const HitRec& h, Ray& r, float u0,
                              float u1) {
     const rt_material m = S.mats[S.mat_id[h.sphere]];
+    const f3 ud = normalize(r.d);
+    const float dn = dot(ud, h.n);
     f3 albedo, dir;
-    if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
-        dir = h.n + map_unit_sphere(u0, u1);
-        if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard
-        albedo = texture_value(S, lds_tables, m.texture_id, h.p);
-    } else if (m.type == RT_MAT_METAL) {  // material.rs:61-72
-        const f3 fz = map_unit_sphere(u0, u1) * m.fuzz;
-        dir = reflect_unit(normalize(r.d), h.n) + fz;
-        if (dot(dir, h.n) <= 0.0f) dir = dir - fz * 2.0f;
-        albedo = {m.albedo[0], m.albedo[1], m.albedo[2]};
-    } else {  // material.rs:91-111
-        const float eta = h.front ? 1.0f / m.ior : m.ior;
-        const f3 ud = normalize(r.d);
-        const float cos_t = fminf(-dot(ud, h.n), 1.0f);
-        const float sin_t = sqrtf(1.0f - cos_t * cos_t);
+    if (m.type == RT_MAT_DIELECTRIC) {  // material.rs:91-111
+        const float eta = h.front ? fast_rcp(m.ior) : m.ior;
+        const float cos_t = fminf(-dn, 1.0f);
+        const float sin_t = fast_sqrt(fmaxf(0.0f, 1.0f - cos_t * cos_t));
         if (eta * sin_t > 1.0f || u0 < schlick(cos_t, eta)) {
             dir = reflect_unit(ud, h.n);  // reflect() re-normalises a unit vector: identity up to rounding
         } else {  // vec3.rs:118-123; cos re-derived un-clamped as the reference does
-            const float c2 = -dot(ud, h.n);
-            const f3 par = (ud + h.n * c2) * eta;
-            const float k = sqrtf(fmaxf(0.0f, 1.0f - dot(par, par)));
+            const f3 par = (ud + h.n * (-dn)) * eta;
+            const float k = fast_sqrt(fmaxf(0.0f, 1.0f - dot(par, par)));
             dir = par - h.n * k;
         }
         albedo = {1.0f, 1.0f, 1.0f};
+    } else {
+        const f3 sph = map_unit_sphere(u0, u1);
+        if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
+            dir = h.n + sph;
+            if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard (deviations)
+            albedo = texture_value(S, lds_tables, m.texture_id, h.p);
+        } else {  // material.rs:61-72
+            const f3 fz = sph * m.fuzz;
+            dir = reflect_unit(ud, h.n) + fz;
+            if (dot(dir, h.n) <= 0.0f) dir = dir - fz * 2.0f;
+            albedo = {m.albedo[0], m.albedo[1], m.albedo[2]};
+        }
     }
     r.o = h.p;
     r.d = dir;

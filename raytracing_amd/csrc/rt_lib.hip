@@ -466,10 +466,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
 
     std::vector<float4> stat, mov_a, mov_b;
     std::vector<int32_t> stat_id, mov_id, big_id;
+    std::vector<float> inv_rad(s->n_spheres);
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         if (s->material_id[i] >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "sphere material_id out of range");
         const float r = s->radius[i];
         if (!(r > 0.0f) || !std::isfinite(r)) return fail(c, RT_ERR_BAD_ARG, "sphere radius must be finite and > 0");
+        inv_rad[i] = (float)(1.0 / (double)r);
         const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
         const float cm = std::fmax(std::fmax(std::fabs(s->c0x[i]), std::fabs(s->c0y[i])), std::fabs(s->c0z[i]));
         if (r >= kBigRadius || cm >= kBigCenter) {
@@ -511,6 +513,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, s->dcy, (size_t)s->n_spheres, &D.dcy));
     UP(dev_copy(c, s->dcz, (size_t)s->n_spheres, &D.dcz));
     UP(dev_copy(c, s->radius, (size_t)s->n_spheres, &D.rad));
+    UP(dev_copy(c, inv_rad.data(), inv_rad.size(), &D.inv_rad));
     UP(dev_copy(c, s->material_id, (size_t)s->n_spheres, &D.mat_id));
     UP(dev_copy(c, s->materials, (size_t)s->n_materials, &D.mats));
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
@@ -572,7 +575,7 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     const uint32_t blocks_x = (A.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
     const uint64_t max_samples_per_launch = 1ull << 31;
     uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
-    const uint64_t target_waves = (uint64_t)c->cu_count * 16 * 12;
+    const uint64_t target_waves = (uint64_t)c->cu_count * 8 * 8;  // ~8 grid waves per resident wave slot
     uint32_t done = 0, launches = 0;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     while (done < p->spp) {

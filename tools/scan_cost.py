@@ -11,11 +11,12 @@ for k in (1, 9, 33, 65, 129, 257, 385, full):
     s = w.scene
     s.n_spheres = k
     ctx.upload(s)
-    p = api.make_params(600, 400, 128, seed=3)
+    p = api.make_params(1200, 800, 64, seed=3)
+    p.reserved = 64  # one chunk: 4096 items per wave, so the per-wave tail does not pollute the fit
     ctx.render(w.camera, p)
     _, st = ctx.render(w.camera, p)
     clk = 2.39e9
-    cyc_per_ray_wave = st.kernel_ms * 1e-3 * clk * 1024 / (st.rays_traced / 64)
+    cyc_per_ray_wave = st.kernel_ms * 1e-3 * clk * 1024 / (st.rays_traced / 128)  # per wave-pass: 64 lanes x 2 paths
     rows.append((k, cyc_per_ray_wave))
     print(f"n={k:4d} rays/sample {st.rays_traced/st.samples:.2f} kernel_ms {st.kernel_ms:8.2f} Grays/s {st.rays_traced/st.kernel_ms/1e6:6.2f} SIMD-cycles per wave-ray {cyc_per_ray_wave:9.0f}")
 a = np.array(rows, float)
