@@ -171,15 +171,20 @@ def cpu_baseline():
     cores = min(16, os.cpu_count() or 1)
     w = api.World("FinalStatic", seed=1, aspect=W / H)
     p = api.make_params(W, H, SPP, seed=w.render_seed)
-    _, sec, rays = orc.render(w.scene, w.camera, p, mode=orc.MODE_REFERENCE, bvh_first=w.bvh_first, bvh_seed=1,
-                              n_threads=cores, precision=64)
+    # configs[0] takes ~0.5 s on 16 cores: repeat it so the sample is ~15-30 core-seconds, report the median pass
+    runs = []
+    for _ in range(5):
+        _, sec, rays = orc.render(w.scene, w.camera, p, mode=orc.MODE_REFERENCE, bvh_first=w.bvh_first, bvh_seed=1,
+                                  n_threads=cores, precision=64)
+        runs.append((sec, rays))
+    sec, rays = sorted(runs)[len(runs) // 2]
     return {
         "value": W * H * SPP / sec,
         "unit": "samples/s",
         "cores": cores,
         "kind": "port",
         "sample": f"all of configs[0]: FinalStatic {W}x{H} @ {SPP} spp, f64, BVH, reference samplers, "
-                  f"{cores} threads over rows ({sec:.2f} s)",
+                  f"{cores} threads over rows (median of 5 passes, {sec:.2f} s each)",
         "mrays_per_s": rays / sec / 1e6,
         "seconds": sec,
     }
