@@ -271,8 +271,9 @@ __device__ __forceinline__ int resolve_slot(const DevScene& S, int slot, float o
 
 // ------------------------------------------------------------------ the f64 sphere test
 // shape.rs:35-65 / :101-133 verbatim in f64 on the fp32 inputs, unnormalised direction:
-// near root if t_min <= t < t_max else far root.  `clamp_disc`: the fp32 scan already decided
-// "hit", so a discriminant that f64 puts a hair below zero is a grazing hit, not a miss.
+// near root if t_min <= t < t_max else far root.  The fp32 scan only NOMINATES a sphere; this f64 test DECIDES
+// it, so a grazing or far-origin false positive of the scan is rejected here (the ray then keeps its big-sphere
+// hit or misses).  `clamp_disc` clamps nothing but f64 rounding noise (|disc| < 1e-14 hb^2) to a tangent hit.
 __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
                                                double t_min, double t_max, bool clamp_disc, double& t_out,
                                                double c_out[3]) {
@@ -286,7 +287,7 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     const double hb = ocx * dx + ocy * dy + ocz * dz;
     const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
     double disc = hb * hb - a * c;
-    if (clamp_disc) disc = fmax(disc, 0.0);
+    if (clamp_disc && disc < 0.0 && disc > -1e-14 * hb * hb) disc = 0.0;  // f64 rounding only
     if (!(disc >= 0.0)) return false;
     const double root = sqrt(disc);
     double t = (-hb - root) * inv_a;  // one f64 reciprocal per ray instead of a division per root
