@@ -21,7 +21,17 @@
 
 namespace rtd {
 
-constexpr int kChunk = 8;           // spheres per scan chunk (winner id is recovered per chunk)
+constexpr int kChunk = 8;           // scan lists are padded to a multiple of this
+#ifndef RT_GROUP
+#define RT_GROUP 4
+#endif
+#ifndef RT_TAILCOND2
+#define RT_TAILCOND2 __builtin_amdgcn_ballot_w64(hit[k] >= 0) != 0
+#endif
+#ifndef RT_TAILCOND
+#define RT_TAILCOND __builtin_amdgcn_ballot_w64(any >= 0) != 0
+#endif
+constexpr int kGroup = RT_GROUP;    // spheres per lazy-root group of the scan (divides kChunk)
 constexpr uint32_t kInfBits = 0x7F800000u;
 constexpr float kTwoPow32 = 4294967296.0f;
 
@@ -175,98 +185,112 @@ struct Pair {
     f2 time;
 };
 
-__device__ __forceinline__ void keys_finish(f2 b, f2 q, uint32_t& ka, uint32_t& kb) {
-    const f2 disc = fma2(b, b, -q);
-    const float sa = __builtin_amdgcn_sqrtf(disc.x), sb = __builtin_amdgcn_sqrtf(disc.y);  // NaN for disc < 0
-    const f2 sx = {__builtin_copysignf(sa, q.x), __builtin_copysignf(sb, q.y)};
-    const f2 t = b - sx;
-    ka = __float_as_uint(t.x);
-    kb = __float_as_uint(t.y);
-}
-// static sphere s = {cx, cy, cz, -r^2}
-__device__ __forceinline__ void keys_static(v4f s, const Pair& r, uint32_t& ka, uint32_t& kb) {
+// b and q of one sphere for both rays.  static sphere s = {cx, cy, cz, -r^2}
+__device__ __forceinline__ void terms_static(v4f s, const Pair& r, f2& b, f2& q) {
     const f2 ocx = s.x - r.ox, ocy = s.y - r.oy, ocz = s.z - r.oz;
-    const f2 b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
-    const f2 q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{s.w, s.w})));
-    keys_finish(b, q, ka, kb);
+    b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
+    q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{s.w, s.w})));
 }
 // moving sphere a = {c0, -r^2}, m = {dc, 0}: center(time) = c0 + time*dc (shape.rs:96-98)
-__device__ __forceinline__ void keys_moving(v4f a, v4f m, const Pair& r, uint32_t& ka, uint32_t& kb) {
+__device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b, f2& q) {
     const f2 ocx = fma2(r.time, f2{m.x, m.x}, a.x - r.ox), ocy = fma2(r.time, f2{m.y, m.y}, a.y - r.oy),
              ocz = fma2(r.time, f2{m.z, m.z}, a.z - r.oz);
-    const f2 b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
-    const f2 q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
-    keys_finish(b, q, ka, kb);
+    b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
+    q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
+}
+// Root extraction for one ray of one sphere whose line test passed somewhere in the wave.  Strict <: the
+// first sphere in list order keeps a tie (hit.rs:100-110 narrows t_max with a half-open range).
+__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, uint32_t& best, int& idx) {
+    const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
+    const uint32_t key = __float_as_uint(b - __builtin_copysignf(s, q));
+    const bool closer = key < best;
+    best = closer ? key : best;
+    idx = closer ? slot : idx;
+}
+
+#ifdef RT_STATS
+__device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres taken, 3 ray-roots useful (disc>=0), 4 ray-roots in front
+#define RT_STAT(i, n) dbg[i] += (n)
+#else
+#define RT_STAT(i, n)
+#endif
+// The root-extraction side of a group: second level, per sphere, again wave-uniform (about one sphere in four
+// of a group that got here is met by some lane).
+__device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (&q)[kGroup], const f2 (&disc)[kGroup],
+                                               const int (&hit)[kGroup], int slot0, uint32_t& best_a, uint32_t& best_b,
+                                               int& idx_a, int& idx_b, unsigned* dbg) {
+#pragma unroll
+    for (int k = 0; k < kGroup; ++k) {
+        if (RT_TAILCOND2) {
+            RT_STAT(2, 1);
+            RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0)));
+            RT_STAT(4, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0))) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))));
+            RT_STAT(5, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0)) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))) != 0);
+            RT_STAT(6, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0) && __float_as_uint(b[k].x - 1.0f) < best_a) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0) && __float_as_uint(b[k].y - 1.0f) < best_b)) != 0);
+            take_root(b[k].x, q[k].x, disc[k].x, slot0 + k, best_a, idx_a);
+            take_root(b[k].y, q[k].y, disc[k].y, slot0 + k, best_b, idx_b);
+        }
+    }
 }
 
 // Scan both lists for both rays.  best[] enter as the bounds from the big-sphere test (or +inf bits).  On
-// return slot[i] is the chunk base (static: [0, ns_pad), moving: ns_pad + [0, nm_pad)) of the chunk that
-// produced ray i's final minimum, or stays -1 when no small sphere beat the incoming bound.
+// return idx[i] is the scan slot (static: [0, ns_pad), moving: ns_pad + [0, nm_pad)) of ray i's closest small
+// sphere, or stays -1 when none beat the incoming bound.
+//
+// The packed arithmetic up to disc = b^2 - q (the reference's 17 / 23 flops, shape.rs:36-40,102-108) runs for
+// every sphere; the un-packable root extraction (v_sqrt, v_bfi, subtract, compare, two selects: 12 instructions
+// for the two rays) runs only for a GROUP of kGroup spheres in which some lane's line meets a sphere
+// (disc >= 0 <=> sign bit clear; one v_max3_i32 per sphere folds the 2*kGroup sign bits, one compare and one
+// wave-uniform branch per group decide).  Upload orders the lists along a Morton curve so the spheres of a group
+// are neighbours and the groups a wave's rays meet are few.
 __device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, uint32_t& best_a, uint32_t& best_b,
-                                             int& slot_a, int& slot_b) {
+                                             int& idx_a, int& idx_b) {
+    unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
-    for (int base = 0; base < S.ns_pad; base += kChunk) {
-        const uint32_t pa = best_a, pb = best_b;
+    if (S.ns_pad > 0) {
+        // software pipeline: the next group's scalar loads are in flight while this group is computed
+        v4f cur[kGroup];
 #pragma unroll
-        for (int k = 0; k < kChunk; k += 2) {
-            uint32_t a0, b0, a1, b1;
-            keys_static(st[base + k], r, a0, b0);
-            keys_static(st[base + k + 1], r, a1, b1);
-            best_a = umin3(best_a, a0, a1);
-            best_b = umin3(best_b, b0, b1);
+        for (int k = 0; k < kGroup; ++k) cur[k] = st[k];
+        for (int base = 0; base < S.ns_pad; base += kGroup) {
+            v4f nxt[kGroup];
+            const int nb = min(base + kGroup, S.ns_pad - kGroup);
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) nxt[k] = st[nb + k];
+            f2 b[kGroup], q[kGroup], disc[kGroup];
+            int any = (int)0x80000000, hit[kGroup];
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                terms_static(cur[k], r, b[k], q[k]);
+                disc[k] = fma2(b[k], b[k], -q[k]);
+                hit[k] = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
+                any = max(any, hit[k]);
+            }
+            RT_STAT(0, 1);
+            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, hit, base, best_a, best_b, idx_a, idx_b, dbg); }
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) cur[k] = nxt[k];
         }
-        slot_a = (best_a != pa) ? base : slot_a;
-        slot_b = (best_b != pb) ? base : slot_b;
     }
     const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
-    for (int base = 0; base < S.nm_pad; base += kChunk) {
-        const uint32_t pa = best_a, pb = best_b;
+    for (int base = 0; base < S.nm_pad; base += kGroup) {
+        f2 b[kGroup], q[kGroup], disc[kGroup];
+        int any = (int)0x80000000, hit[kGroup];
 #pragma unroll
-        for (int k = 0; k < kChunk; k += 2) {
-            uint32_t a0, b0, a1, b1;
-            keys_moving(ma[base + k], mb[base + k], r, a0, b0);
-            keys_moving(ma[base + k + 1], mb[base + k + 1], r, a1, b1);
-            best_a = umin3(best_a, a0, a1);
-            best_b = umin3(best_b, b0, b1);
+        for (int k = 0; k < kGroup; ++k) {
+            terms_moving(ma[base + k], mb[base + k], r, b[k], q[k]);
+            disc[k] = fma2(b[k], b[k], -q[k]);
+            hit[k] = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
+            any = max(any, hit[k]);
         }
-        slot_a = (best_a != pa) ? S.ns_pad + base : slot_a;
-        slot_b = (best_b != pb) ? S.ns_pad + base : slot_b;
+        RT_STAT(0, 1);
+        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, hit, S.ns_pad + base, best_a, best_b, idx_a, idx_b, dbg); }
     }
-}
-
-// Which of the 8 spheres of chunk `slot` is the closest for ONE ray: per-lane gather (L1/L2), once per
-// bounce.  Same arithmetic as the scan, unpacked.
-__device__ __forceinline__ uint32_t key_one(float cx, float cy, float cz, float w, float ox, float oy, float oz,
-                                            float dx, float dy, float dz) {
-    const float ocx = cx - ox, ocy = cy - oy, ocz = cz - oz;
-    const float b = fmaf(ocz, dz, fmaf(ocy, dy, ocx * dx));
-    const float q = fmaf(ocz, ocz, fmaf(ocy, ocy, fmaf(ocx, ocx, w)));
-    const float disc = fmaf(b, b, -q);
-    const float s = __builtin_amdgcn_sqrtf(disc);
-    return __float_as_uint(b - __builtin_copysignf(s, q));
-}
-__device__ __forceinline__ int resolve_slot(const DevScene& S, int slot, float ox, float oy, float oz, float dx,
-                                            float dy, float dz, float time) {
-    uint32_t best = 0xFFFFFFFFu;
-    int idx = slot;
-    if (slot < S.ns_pad) {
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) {
-            const float4 a = S.stat[slot + k];
-            const uint32_t key = key_one(a.x, a.y, a.z, a.w, ox, oy, oz, dx, dy, dz);
-            if (key < best) { best = key; idx = slot + k; }
-        }
-    } else {
-        const int m = slot - S.ns_pad;
-#pragma unroll
-        for (int k = 0; k < kChunk; ++k) {
-            const float4 a = S.mov_a[m + k], d = S.mov_b[m + k];
-            const uint32_t key = key_one(fmaf(time, d.x, a.x), fmaf(time, d.y, a.y), fmaf(time, d.z, a.z), a.w, ox,
-                                         oy, oz, dx, dy, dz);
-            if (key < best) { best = key; idx = slot + k; }
-        }
-    }
-    return idx;
+#ifdef RT_STATS
+    if ((threadIdx.x & 63) == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg[i], (unsigned long long)dbg[i]);
+#endif
+    (void)dbg;
 }
 
 // ------------------------------------------------------------------ the f64 sphere test
@@ -332,11 +356,10 @@ __device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, f
     return __float_as_uint(fmaxf(tb, 0.0f));
 }
 __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float t_min, HitWork& w, uint32_t best,
-                                          int slot, float ox, float oy, float oz, float dx, float dy, float dz) {
+                                          int slot) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     if (slot >= 0 && best < kInfBits) {  // the scan's winner, re-derived in f64 for the hit record
-        const int idx = resolve_slot(S, slot, ox, oy, oz, dx, dy, dz, r.time);
-        const int id = S.scan_id[idx];
+        const int id = S.scan_id[slot];
         double t, c[3];
         if (id >= 0 && sphere_hit_f64(S, id, r, w.a, w.inv_a, (double)t_min, inf, true, t, c) && t < w.t_best) {
             w.t_best = t; w.id_best = id;
@@ -382,12 +405,16 @@ __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, c
     p.oy = f2{fmaf(t_min, ra.d.y, ra.o.y), fmaf(t_min, rb.d.y, rb.o.y)};
     p.oz = f2{fmaf(t_min, ra.d.z, ra.o.z), fmaf(t_min, rb.d.z, rb.o.z)};
     p.time = f2{ra.time, rb.time};
+    // a dead ray rides through the packed scan: park it (d = 0, far origin => disc = -|oc|^2 - ... < 0 for every
+    // sphere) so it never sends its wave into a root-extraction group
+    if (!do_a) { p.dx.x = p.dy.x = p.dz.x = 0.0f; p.ox.x = 1e18f; p.oy.x = p.oz.x = 0.0f; p.time.x = 0.0f; }
+    if (!do_b) { p.dx.y = p.dy.y = p.dz.y = 0.0f; p.ox.y = 1e18f; p.oy.y = p.oz.y = 0.0f; p.time.y = 0.0f; }
     int slot_a = -1, slot_b = -1;
     scan_spheres(S, p, best_a, best_b, slot_a, slot_b);
     ha.sphere = -1;
     hb.sphere = -1;
-    if (do_a) ha = hit_end(S, ra, t_min, wa, best_a, slot_a, p.ox.x, p.oy.x, p.oz.x, p.dx.x, p.dy.x, p.dz.x);
-    if (do_b) hb = hit_end(S, rb, t_min, wb, best_b, slot_b, p.ox.y, p.oy.y, p.oz.y, p.dx.y, p.dy.y, p.dz.y);
+    if (do_a) ha = hit_end(S, ra, t_min, wa, best_a, slot_a);
+    if (do_b) hb = hit_end(S, rb, t_min, wb, best_b, slot_b);
 }
 
 // ------------------------------------------------------------------ textures

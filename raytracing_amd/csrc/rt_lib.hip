@@ -4,7 +4,10 @@
 // Replaces reference main.rs:64-92 (rayon pixel/sample loop) + main.rs:110-139 (ray_color).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <numeric>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -485,6 +488,58 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             stat_id.push_back((int32_t)i);
         }
     }
+    // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
+    // group are then neighbours, so the groups met by a wave's rays are few (rt_device.h, scan_spheres).  Ties in
+    // the curve keep world order (stable sort); RTX_SCAN_ORDER=world keeps the caller's order (A/B switch).
+    const char* order_env = std::getenv("RTX_SCAN_ORDER");
+    if (!(order_env && std::strcmp(order_env, "world") == 0)) {
+        auto morton_order = [](const std::vector<float4>& ctr) {
+            std::vector<uint32_t> perm(ctr.size());
+            std::iota(perm.begin(), perm.end(), 0u);
+            if (ctr.size() < 2) return perm;
+            float lo[3] = {ctr[0].x, ctr[0].y, ctr[0].z}, hi[3] = {ctr[0].x, ctr[0].y, ctr[0].z};
+            for (const float4& v : ctr) {
+                const float p3[3] = {v.x, v.y, v.z};
+                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p3[a]); hi[a] = std::fmax(hi[a], p3[a]); }
+            }
+            const float ext = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), std::fmax(hi[2] - lo[2], 1e-30f));
+            auto spread = [](uint64_t v) {  // 21 bits -> every third bit
+                v &= 0x1FFFFF;
+                v = (v | v << 32) & 0x1F00000000FFFFull;
+                v = (v | v << 16) & 0x1F0000FF0000FFull;
+                v = (v | v << 8) & 0x100F00F00F00F00Full;
+                v = (v | v << 4) & 0x10C30C30C30C30C3ull;
+                v = (v | v << 2) & 0x1249249249249249ull;
+                return v;
+            };
+            std::vector<uint64_t> code(ctr.size());
+            for (size_t i = 0; i < ctr.size(); ++i) {
+                const float p3[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
+                uint64_t m = 0;
+                for (int a = 0; a < 3; ++a) {
+                    const double u = ((double)p3[a] - (double)lo[a]) / (double)ext;  // cubic cells: one scale for all axes
+                    m |= spread((uint64_t)std::fmin(std::fmax(u, 0.0) * 2097151.0, 2097151.0)) << a;
+                }
+                code[i] = m;
+            }
+            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
+            return perm;
+        };
+        {
+            const std::vector<uint32_t> perm = morton_order(stat);
+            std::vector<float4> s2(stat.size());
+            std::vector<int32_t> i2(stat.size());
+            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = stat[perm[k]]; i2[k] = stat_id[perm[k]]; }
+            stat.swap(s2); stat_id.swap(i2);
+        }
+        {
+            const std::vector<uint32_t> perm = morton_order(mov_a);  // by the centre at time 0
+            std::vector<float4> a2(mov_a.size()), b2(mov_a.size());
+            std::vector<int32_t> i2(mov_a.size());
+            for (size_t k = 0; k < perm.size(); ++k) { a2[k] = mov_a[perm[k]]; b2[k] = mov_b[perm[k]]; i2[k] = mov_id[perm[k]]; }
+            mov_a.swap(a2); mov_b.swap(b2); mov_id.swap(i2);
+        }
+    }
     while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, 1.0f)); stat_id.push_back(-1); }
     while (mov_a.size() % kChunk) {
         mov_a.push_back(make_float4(0, 0, 0, 1.0f));
@@ -754,3 +809,14 @@ int rt_encode(rt_ctx* c, const float* rgb, uint32_t n_pixels, uint32_t* out_0rgb
 }
 
 }  // extern "C"
+
+#ifdef RT_STATS
+extern "C" int rt_debug_counters(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(rtd::g_dbg), sizeof(unsigned long long) * 8) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(rtd::g_dbg), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
