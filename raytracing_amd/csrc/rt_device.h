@@ -31,6 +31,9 @@ constexpr int kChunk = 8;           // scan lists are padded to a multiple of th
 #ifndef RT_TAILCOND
 #define RT_TAILCOND __builtin_amdgcn_ballot_w64(any >= 0) != 0
 #endif
+#ifndef RT_ASM_PREFETCH
+#define RT_ASM_PREFETCH 1
+#endif
 constexpr int kGroup = RT_GROUP;    // spheres per lazy-root group of the scan (divides kChunk)
 constexpr uint32_t kInfBits = 0x7F800000u;
 constexpr float kTwoPow32 = 4294967296.0f;
@@ -247,30 +250,68 @@ __device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, u
                                              int& idx_a, int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
+#ifdef RT_NOSCAN
+    if (false) {
+#else
     if (S.ns_pad > 0) {
-        // software pipeline: the next group's scalar loads are in flight while this group is computed
-        v4f cur[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) cur[k] = st[k];
-        for (int base = 0; base < S.ns_pad; base += kGroup) {
-            v4f nxt[kGroup];
-            const int nb = min(base + kGroup, S.ns_pad - kGroup);
-#pragma unroll
-            for (int k = 0; k < kGroup; ++k) nxt[k] = st[nb + k];
+#endif
+        // Software pipeline over two register sets: while one group is computed the next group's 16 SGPRs are
+        // in flight (SMEM returns out of order, so the wait is always lgkmcnt(0): the load must be a whole
+        // group ahead to hide its latency with only four waves per SIMD).  ns_pad is a multiple of 2 * kGroup.
+        auto group = [&](const v4f (&sp)[kGroup], int base) {
             f2 b[kGroup], q[kGroup], disc[kGroup];
             int any = (int)0x80000000, hit[kGroup];
 #pragma unroll
             for (int k = 0; k < kGroup; ++k) {
-                terms_static(cur[k], r, b[k], q[k]);
+                terms_static(sp[k], r, b[k], q[k]);
                 disc[k] = fma2(b[k], b[k], -q[k]);
                 hit[k] = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
                 any = max(any, hit[k]);
             }
             RT_STAT(0, 1);
             if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, hit, base, best_a, best_b, idx_a, idx_b, dbg); }
+        };
+#if RT_ASM_PREFETCH
+        static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
+        typedef float v16f __attribute__((ext_vector_type(16)));
+        auto unpack = [](const v16f& v, v4f (&sp)[kGroup]) {
 #pragma unroll
-            for (int k = 0; k < kGroup; ++k) cur[k] = nxt[k];
+            for (int k = 0; k < kGroup; ++k) sp[k] = v4f{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
+        };
+        v16f va, vb;
+        const cv4p p0 = st;
+        asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(va) : "s"(p0));
+        for (int base = 0; base < S.ns_pad; base += 2 * kGroup) {
+            asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(va));
+            const cv4p pb = st + base + kGroup;
+            asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(vb) : "s"(pb));
+            __builtin_amdgcn_sched_barrier(0);
+            v4f ga[kGroup];
+            unpack(va, ga);
+            group(ga, base);
+            asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(vb));
+            const cv4p pa = st + min(base + 2 * kGroup, S.ns_pad - kGroup);
+            asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(va) : "s"(pa));
+            __builtin_amdgcn_sched_barrier(0);
+            v4f gb[kGroup];
+            unpack(vb, gb);
+            group(gb, base + kGroup);
         }
+        asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(va));
+#else
+        v4f ga[kGroup], gb[kGroup];
+#pragma unroll
+        for (int k = 0; k < kGroup; ++k) ga[k] = st[k];
+        for (int base = 0; base < S.ns_pad; base += 2 * kGroup) {
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) gb[k] = st[base + kGroup + k];
+            group(ga, base);
+            const int nb = min(base + 2 * kGroup, S.ns_pad - kGroup);
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) ga[k] = st[nb + k];
+            group(gb, base + kGroup);
+        }
+#endif
     }
     const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
     for (int base = 0; base < S.nm_pad; base += kGroup) {

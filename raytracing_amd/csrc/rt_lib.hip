@@ -25,6 +25,7 @@ namespace {
 constexpr int kBlock = 256;          // 4 waves per workgroup share one LDS copy of the scene
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
+constexpr uint32_t kUnitSpp = 32;    // samples per pixel of one work unit (8x8 pixels x 32 spp = 2048 items, ~45 scan passes)
 constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
 constexpr float kBigCenter = 500.0f;
 
@@ -34,7 +35,8 @@ struct RenderArgs {
     uint32_t W, H, tiles_x, n_tiles;
     uint32_t spp_first;      // absolute index of this launch's first sample
     uint32_t spp_count;      // samples per pixel in this launch
-    uint32_t spp_per_chunk;  // blockIdx.y picks [y*spp_per_chunk, ...) of them
+    uint32_t spp_per_chunk;  // chunk k covers samples [k*spp_per_chunk, ...) of them
+    uint32_t n_units;        // work units of this launch = n_tiles * chunks; unit u = (tile u % n_tiles, chunk u / n_tiles)
     uint32_t max_depth;
     int32_t antialias;
     uint32_t k0, k1;
@@ -42,59 +44,91 @@ struct RenderArgs {
     uint32_t lds_scene_bytes;
     unsigned long long* accum;  // W*H*3 fixed-point (2^-32) radiance sums
     unsigned long long* rays;
+    unsigned int* unit_counter;  // next unclaimed work unit (zeroed before the launch)
 };
 
-// One wave = one 8x8 tile x one spp chunk, and every lane carries TWO paths (the packed scan tests both
-// against each sphere in one instruction stream).  The wave runs a private work queue of (pixel, sample)
-// items: a path slot whose path ended takes the next item, so every slot has a live ray in (almost) every
-// pass of the sphere scan regardless of how path lengths differ.  Radiance is summed in 2^-32 fixed point
-// (order-independent => bit-reproducible images whatever the chunking, tiling or lane scheduling): LDS per
-// wave, then one global atomic per pixel-channel.
+// PERSISTENT waves over a queue of work units.  The grid is exactly the waves the GPU holds at once; a unit is
+// one 8x8 pixel tile x one chunk of samples, claimed with one atomic per unit, so all SIMDs stay busy until the
+// queue is empty however uneven the path lengths are (no last-round tail of a static grid).  Every lane carries
+// TWO paths (the packed scan tests both against each sphere in one instruction stream).  Inside a unit the wave
+// runs a private queue of (pixel, sample) items: a path slot whose path ended takes the next item, and when the
+// unit's items run out the wave claims the next unit WITHOUT draining: paths of the old unit still in flight
+// finish as "orphans" that add straight into the global accumulators.  Radiance is summed in 2^-32 fixed point
+// (order-independent => bit-reproducible images whatever the chunking, tiling or scheduling): LDS per wave and
+// tile, then one global atomic per pixel-channel at the end of a unit.
 struct PathState {
     Ray ray;
     f3 thr;
     uint32_t pix_local, pix, smp, depth;
-    bool alive;
+    bool alive, orphan;
 };
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4  // <= 128 VGPRs: 4 waves per SIMD measured fastest (2: 27.6 %, 3: 29.2 %, 4: 29.5 % of peak)
+#define RT_WAVES_PER_EU 4  // <= 128 VGPRs; 2, 3 and 4 waves per SIMD measure within 2 % of each other
 #endif
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const LdsScene L = stage_scene(A.S, lds, tid, kBlock);
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes) + wave * 192;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes) + wave * 192;  // wave-private
     acc[lane] = 0; acc[lane + 64] = 0; acc[lane + 128] = 0;
-
-    const uint32_t tile = blockIdx.x * kWavesPerBlock + wave;
-    const uint32_t s_lo = blockIdx.y * A.spp_per_chunk;
-    const uint32_t s_n = (s_lo < A.spp_count) ? min(A.spp_per_chunk, A.spp_count - s_lo) : 0u;
-    uint32_t tx0 = 0, ty0 = 0, tw = 0, th = 0;
-    if (tile < A.n_tiles) {
-        tx0 = (tile % A.tiles_x) * kTile;
-        ty0 = (tile / A.tiles_x) * kTile;
-        tw = min((uint32_t)kTile, A.W - tx0);
-        th = min((uint32_t)kTile, A.H - ty0);
-    }
-    const uint32_t npix = tw * th;
-    const uint32_t total = npix * s_n;  // items of this wave
     const float inv_w = 1.0f / ((float)A.W - 1.0f), inv_h = 1.0f / ((float)A.H - 1.0f);
 
-    uint32_t next = 0;
+    // current unit (wave-uniform)
+    uint32_t tx0 = 0, ty0 = 0, tw = 1, npix = 0, s_lo = 0;
+    uint32_t next = 0, total = 0;
+    bool more = true;  // the unit queue may still hold work
+
     PathState ps[2];
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         ps[s].ray = {{0, 0, 0}, {0, 0, 1}, 0};
         ps[s].thr = {1, 1, 1};
         ps[s].pix_local = ps[s].pix = ps[s].smp = ps[s].depth = 0;
-        ps[s].alive = false;
+        ps[s].alive = ps[s].orphan = false;
     }
     unsigned long long n_rays = 0;
 
+    // the unit's tile: LDS sums -> global accumulators, LDS cleared (the region is private to this wave)
+    auto flush_tile = [&]() {
+        if ((uint32_t)lane < npix) {
+            const uint32_t ly = lane / tw, lx = lane - ly * tw;
+            unsigned long long* g = A.accum + ((size_t)(ty0 + ly) * A.W + (tx0 + lx)) * 3;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const unsigned long long q = acc[lane * 3 + k];
+                if (q) atomicAdd(g + k, q);
+                acc[lane * 3 + k] = 0;
+            }
+        }
+    };
+
     for (;;) {
-        // ---- refill dead path slots from the wave's queue
+        // ---- unit queue: claim the next unit once this one has no items left and a slot is free
+        if (next >= total && more && __ballot(!ps[0].alive || !ps[1].alive) != 0ull) {
+            flush_tile();
+            ps[0].orphan = ps[0].alive;
+            ps[1].orphan = ps[1].alive;
+            uint32_t u = 0;
+            if (lane == 0) u = atomicAdd(A.unit_counter, 1u);
+            u = __builtin_amdgcn_readfirstlane(u);
+            next = 0;
+            if (u < A.n_units) {
+                const uint32_t tile = u % A.n_tiles, chunk = u / A.n_tiles;
+                tx0 = (tile % A.tiles_x) * kTile;
+                ty0 = (tile / A.tiles_x) * kTile;
+                tw = min((uint32_t)kTile, A.W - tx0);
+                npix = tw * min((uint32_t)kTile, A.H - ty0);
+                s_lo = chunk * A.spp_per_chunk;
+                total = npix * min(A.spp_per_chunk, A.spp_count - s_lo);
+            } else {
+                more = false;
+                npix = 0;
+                total = 0;
+            }
+        }
+        // ---- refill dead path slots from the unit's items
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
@@ -125,11 +159,15 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                     P.thr = {1.0f, 1.0f, 1.0f};
                     P.depth = 0;
                     P.alive = true;
+                    P.orphan = false;
                 }
             }
-            next += (uint32_t)__popcll(need);
+            next = min(next + (uint32_t)__popcll(need), total);
         }
-        if (__ballot(ps[0].alive || ps[1].alive) == 0ull) break;
+        if (__ballot(ps[0].alive || ps[1].alive) == 0ull) {
+            if (!more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
+            continue;          // (next >= total here, so the next pass claims a unit or clears `more`)
+        }
 
         // ---- one ray segment per live path: closest hit (both paths in one packed scan), then scatter
         HitRec h[2];
@@ -160,24 +198,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                         float v = c[k];
                         v = (v > 0.0f) ? fminf(v, 1048576.0f) : 0.0f;  // NaN / negative -> 0
                         const unsigned long long q = (unsigned long long)(v * kTwoPow32);
-                        if (q) atomicAdd(&acc[P.pix_local * 3 + k], q);
+                        if (q) {
+                            if (P.orphan) atomicAdd(A.accum + (size_t)P.pix * 3 + k, q);
+                            else atomicAdd(&acc[P.pix_local * 3 + k], q);
+                        }
                     }
                 }
             }
         }
     }
+    flush_tile();  // no-op unless the loop is ever left with a tile open
 
-    // ---- flush the wave's tile
-    __syncthreads();
-    if ((uint32_t)lane < npix && s_n) {
-        const uint32_t ly = lane / tw, lx = lane - ly * tw;
-        unsigned long long* g = A.accum + ((size_t)(ty0 + ly) * A.W + (tx0 + lx)) * 3;
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const unsigned long long q = acc[lane * 3 + k];
-            if (q) atomicAdd(g + k, q);
-        }
-    }
     // ray-segment counter: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off, 64);
     if (lane == 0 && n_rays) atomicAdd(A.rays, n_rays);
@@ -391,7 +422,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev1);
     if (e == hipSuccess) e = hipEventCreate(&c->ev2);
     if (e == hipSuccess) e = hipEventCreate(&c->ev3);
-    if (e == hipSuccess) e = hipMalloc((void**)&c->rays, sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMalloc((void**)&c->rays, 2 * sizeof(unsigned long long));  // [0] ray counter, [1] unit counter
     if (e != hipSuccess) {
         g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
         rt_destroy(c);
@@ -624,25 +655,33 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     A.rays = c->rays;
     const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
 
-    // Launch plan.  A launch renders `spp_l` samples per pixel as grid (tile groups, chunks).
-    // Chunks keep the grid at >= ~48 waves per SIMD-slot so the tail of the last tiles is short;
-    // launches are capped at 2^31 samples so no single kernel runs for minutes.
-    const uint32_t blocks_x = (A.n_tiles + kWavesPerBlock - 1) / kWavesPerBlock;
+    // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * chunks work units that a grid of
+    // persistent waves (as many as the GPU holds at once) pulls from a counter.  A unit is ~2048 items (64 pixels x
+    // 32 samples, ~45 passes of the sphere scan): small enough that the waves finish within a percent of each
+    // other, large enough that the unit switch (one atomic, one tile flush) is noise.  Launches are capped at
+    // 2^31 samples so no single kernel runs for minutes.
     const uint64_t max_samples_per_launch = 1ull << 31;
     uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
-    const uint64_t target_waves = (uint64_t)c->cu_count * 8 * 8;  // ~8 grid waves per resident wave slot
+    int blocks_per_cu = 0;
+    RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, kBlock, lds_bytes));
+    if (blocks_per_cu < 1) return fail(c, RT_ERR_HIP, "render kernel does not fit a compute unit");
+    const uint32_t resident_blocks = (uint32_t)c->cu_count * (uint32_t)blocks_per_cu;
     uint32_t done = 0, launches = 0;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     while (done < p->spp) {
         const uint32_t spp_l = std::min(spp_per_launch, p->spp - done);
-        uint32_t chunks = (uint32_t)std::min<uint64_t>(spp_l, (target_waves + A.n_tiles - 1) / A.n_tiles);
-        chunks = std::max(1u, std::min(chunks, 65535u));
-        if (p->reserved) chunks = std::max(1u, (spp_l + p->reserved - 1) / p->reserved);  // debug/test hook: force spp per chunk
         A.spp_first = p->spp_offset + done;
         A.spp_count = spp_l;
-        A.spp_per_chunk = (spp_l + chunks - 1) / chunks;
-        chunks = (spp_l + A.spp_per_chunk - 1) / A.spp_per_chunk;
-        hipLaunchKernelGGL(render_kernel, dim3(blocks_x, chunks), dim3(kBlock), lds_bytes, c->stream, A);
+        A.spp_per_chunk = std::min(spp_l, kUnitSpp);
+        if (p->reserved) A.spp_per_chunk = std::min(spp_l, p->reserved);  // debug/test hook: force spp per chunk
+        const uint32_t chunks = (spp_l + A.spp_per_chunk - 1) / A.spp_per_chunk;
+        const uint64_t n_units = (uint64_t)A.n_tiles * chunks;
+        if (n_units > 0xFFFFFFF0ull) return fail(c, RT_ERR_BAD_ARG, "too many work units in one launch");
+        A.n_units = (uint32_t)n_units;
+        A.unit_counter = reinterpret_cast<unsigned int*>(c->rays + 1);
+        RT_HIP(c, hipMemsetAsync(c->rays + 1, 0, sizeof(unsigned long long), c->stream));
+        const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
+        hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
         done += spp_l;
         ++launches;

@@ -9,10 +9,12 @@ for scene in sys.argv[1:] or ["FinalStatic"]:
     ctx.upload(w.scene)
     out = (C.c_ulonglong * 8)()
     ctx.lib.rt_debug_counters(out, 1)
-    p = api.make_params(1200, 800, 20, seed=w.render_seed)
+    spp = int(os.environ.get("SPP", "20"))
+    p = api.make_params(1200, 800, spp, seed=w.render_seed)
     img, st = ctx.render(w.camera, p)
     ctx.lib.rt_debug_counters(out, 1)
     g, gt, stk, r_useful, r_front, s_front, s_front_bound = [out[i] for i in range(7)]
+    print("slot utilisation %.4f (rays %d, passes %d, kernel %.1f ms)" % (st.rays_traced / (g / (w.arrays()["radius"].shape[0] // 4 + 0.0) * 128), st.rays_traced, g, st.kernel_ms))
     print(scene, "groups", g, "taken %.3f" % (gt / g), "spheres taken / sphere %.3f" % (stk / (4 * g)),
           "per taken group %.2f" % (stk / max(gt, 1)), "useful ray-roots per taken sphere (of 128) %.2f" % (r_useful / max(stk, 1)),
           "in-front %.2f" % (r_front / max(stk, 1)), "spheres w/ in-front hit / sphere %.3f" % (s_front / (4 * g)),
