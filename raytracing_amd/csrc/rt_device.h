@@ -26,7 +26,7 @@ constexpr int kChunk = 8;           // scan lists are padded to a multiple of th
 #define RT_GROUP 4
 #endif
 #ifndef RT_TAILCOND2
-#define RT_TAILCOND2 __builtin_amdgcn_ballot_w64(hit[k] >= 0) != 0
+#define RT_TAILCOND2 __builtin_amdgcn_ballot_w64(hit >= 0) != 0
 #endif
 #ifndef RT_TAILCOND
 #define RT_TAILCOND __builtin_amdgcn_ballot_w64(any >= 0) != 0
@@ -220,10 +220,11 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 // The root-extraction side of a group: second level, per sphere, again wave-uniform (about one sphere in four
 // of a group that got here is met by some lane).
 __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (&q)[kGroup], const f2 (&disc)[kGroup],
-                                               const int (&hit)[kGroup], int slot0, uint32_t& best_a, uint32_t& best_b,
-                                               int& idx_a, int& idx_b, unsigned* dbg) {
+                                               int slot0, uint32_t& best_a, uint32_t& best_b, int& idx_a, int& idx_b,
+                                               unsigned* dbg) {
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) {
+        const int hit = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
         if (RT_TAILCOND2) {
             RT_STAT(2, 1);
             RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0)));
@@ -260,16 +261,15 @@ __device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, u
         // group ahead to hide its latency with only four waves per SIMD).  ns_pad is a multiple of 2 * kGroup.
         auto group = [&](const v4f (&sp)[kGroup], int base) {
             f2 b[kGroup], q[kGroup], disc[kGroup];
-            int any = (int)0x80000000, hit[kGroup];
+            int any = (int)0x80000000;
 #pragma unroll
             for (int k = 0; k < kGroup; ++k) {
                 terms_static(sp[k], r, b[k], q[k]);
                 disc[k] = fma2(b[k], b[k], -q[k]);
-                hit[k] = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
-                any = max(any, hit[k]);
+                any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));  // one v_max3_i32
             }
             RT_STAT(0, 1);
-            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, hit, base, best_a, best_b, idx_a, idx_b, dbg); }
+            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, base, best_a, best_b, idx_a, idx_b, dbg); }
         };
 #if RT_ASM_PREFETCH
         static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
@@ -316,16 +316,15 @@ __device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, u
     const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
     for (int base = 0; base < S.nm_pad; base += kGroup) {
         f2 b[kGroup], q[kGroup], disc[kGroup];
-        int any = (int)0x80000000, hit[kGroup];
+        int any = (int)0x80000000;
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) {
             terms_moving(ma[base + k], mb[base + k], r, b[k], q[k]);
             disc[k] = fma2(b[k], b[k], -q[k]);
-            hit[k] = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
-            any = max(any, hit[k]);
+            any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
         }
         RT_STAT(0, 1);
-        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, hit, S.ns_pad + base, best_a, best_b, idx_a, idx_b, dbg); }
+        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, S.ns_pad + base, best_a, best_b, idx_a, idx_b, dbg); }
     }
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
@@ -340,8 +339,7 @@ __device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, u
 // it, so a grazing or far-origin false positive of the scan is rejected here (the ray then keeps its big-sphere
 // hit or misses).  `clamp_disc` clamps nothing but f64 rounding noise (|disc| < 1e-14 hb^2) to a tangent hit.
 __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
-                                               double t_min, double t_max, bool clamp_disc, double& t_out,
-                                               double c_out[3]) {
+                                               double t_min, double t_max, bool clamp_disc, double& t_out) {
     const double tm = (double)r.time;
     const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];
     const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
@@ -363,48 +361,47 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     }
     if (!ok) return false;
     t_out = t;
-    c_out[0] = cx; c_out[1] = cy; c_out[2] = cz;
     return true;
 }
 
-// Per-ray state around the packed scan: the f64 big-sphere pass before it and the f64 hit record after it.
+// Per-ray state kept across the packed scan: the f64 big-sphere result before it, the f64 hit record after it.
+// Kept small (7 VGPRs per ray): everything else is recomputed after the scan from the ray and the winner's id.
 struct HitWork {
-    double t_best, c_best[3];
+    double t_best;
+    double inv_a;  // 1 / |d|^2, f64
     int id_best;
-    float inv_len, len;
-    double a, inv_a;  // |d|^2 and its reciprocal, f64
+    float inv_len;
 };
+__device__ __forceinline__ double dir_len2(const Ray& r) {
+    return (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
+}
 __device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, float t_min, HitWork& w) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     w.t_best = inf;
-    w.c_best[0] = w.c_best[1] = w.c_best[2] = 0.0;
     w.id_best = -1;
-    w.a = (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
-    w.inv_a = 1.0 / w.a;
+    const double a = dir_len2(r);
+    w.inv_a = 1.0 / a;
     for (int k = 0; k < S.n_big; ++k) {  // big spheres, f64, world order
-        double t, c[3];
+        double t;
         const int id = S.big_id[k];
-        if (sphere_hit_f64(S, id, r, w.a, w.inv_a, (double)t_min, w.t_best, false, t, c)) {
+        if (sphere_hit_f64(S, id, r, a, w.inv_a, (double)t_min, w.t_best, false, t)) {
             w.t_best = t; w.id_best = id;
-            w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
     }
-    const float len2 = (float)w.a;
+    const float len2 = (float)a;
     w.inv_len = fast_rsq(len2);
-    w.len = len2 * w.inv_len;
     if (w.id_best < 0) return kInfBits;
-    const float tb = (float)((w.t_best - (double)t_min) * (double)w.len);
+    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * w.inv_len));
     return __float_as_uint(fmaxf(tb, 0.0f));
 }
 __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float t_min, HitWork& w, uint32_t best,
                                           int slot) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    if (slot >= 0 && best < kInfBits) {  // the scan's winner, re-derived in f64 for the hit record
+    if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
         const int id = S.scan_id[slot];
-        double t, c[3];
-        if (id >= 0 && sphere_hit_f64(S, id, r, w.a, w.inv_a, (double)t_min, inf, true, t, c) && t < w.t_best) {
+        double t;
+        if (id >= 0 && sphere_hit_f64(S, id, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t) && t < w.t_best) {
             w.t_best = t; w.id_best = id;
-            w.c_best[0] = c[0]; w.c_best[1] = c[1]; w.c_best[2] = c[2];
         }
     }
     HitRec h;
@@ -414,11 +411,16 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
         return h;
     }
     // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
+    const int id = w.id_best;
+    const double tm = (double)r.time;
+    const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];  // shape.rs:96-98 (dc = 0 for a static sphere)
+    const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
+    const double cz = (double)S.c0z[id] + tm * (double)S.dcz[id];
     const double px = (double)r.o.x + w.t_best * (double)r.d.x;
     const double py = (double)r.o.y + w.t_best * (double)r.d.y;
     const double pz = (double)r.o.z + w.t_best * (double)r.d.z;
-    const double ir = (double)S.inv_rad[w.id_best];  // 1/r rounded to fp32: |n| = 1 +- 6e-8
-    double nx = (px - w.c_best[0]) * ir, ny = (py - w.c_best[1]) * ir, nz = (pz - w.c_best[2]) * ir;
+    const double ir = (double)S.inv_rad[id];  // 1/r rounded to fp32: |n| = 1 +- 6e-8
+    double nx = (px - cx) * ir, ny = (py - cy) * ir, nz = (pz - cz) * ir;
     const bool front = ((double)r.d.x * nx + (double)r.d.y * ny + (double)r.d.z * nz) < 0.0;
     if (!front) { nx = -nx; ny = -ny; nz = -nz; }
     h.front = front ? 1 : 0;

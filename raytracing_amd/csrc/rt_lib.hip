@@ -64,7 +64,8 @@ struct PathState {
 };
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 4  // <= 128 VGPRs; 2, 3 and 4 waves per SIMD measure within 2 % of each other
+#define RT_WAVES_PER_EU 3  // 154 VGPRs, no scratch.  2, 3 and 4 waves per SIMD measure within 2 % of each other, but 4
+                           // (128 VGPRs) spills ~3 dwords per lane per pass = 17 GB of scratch writes per launch
 #endif
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A) {
     extern __shared__ __align__(16) unsigned char lds[];
@@ -92,14 +93,15 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
     // the unit's tile: LDS sums -> global accumulators, LDS cleared (the region is private to this wave)
     auto flush_tile = [&]() {
-        if ((uint32_t)lane < npix) {
-            const uint32_t ly = lane / tw, lx = lane - ly * tw;
-            unsigned long long* g = A.accum + ((size_t)(ty0 + ly) * A.W + (tx0 + lx)) * 3;
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const unsigned long long q = acc[lane * 3 + k];
-                if (q) atomicAdd(g + k, q);
-                acc[lane * 3 + k] = 0;
+        // the tile's 3*npix sums are row-major in LDS; lanes take consecutive elements so that the atomics of one
+        // instruction fall on consecutive addresses of (at most three) image rows
+        const uint32_t row = tw * 3, n = npix * 3;
+        for (uint32_t e = lane; e < n; e += 64) {
+            const unsigned long long q = acc[e];
+            if (q) {
+                const uint32_t ly = e / row, rem = e - ly * row;
+                atomicAdd(A.accum + ((size_t)(ty0 + ly) * A.W + tx0) * 3 + rem, q);
+                acc[e] = 0;
             }
         }
     };
@@ -655,11 +657,9 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     A.rays = c->rays;
     const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
 
-    // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * chunks work units that a grid of
-    // persistent waves (as many as the GPU holds at once) pulls from a counter.  A unit is ~2048 items (64 pixels x
-    // 32 samples, ~45 passes of the sphere scan): small enough that the waves finish within a percent of each
-    // other, large enough that the unit switch (one atomic, one tile flush) is noise.  Launches are capped at
-    // 2^31 samples so no single kernel runs for minutes.
+    // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * n_levels work units that a grid of
+    // persistent waves (as many as the GPU holds at once) pulls from a counter.  Launches are capped at 2^31
+    // samples so no single kernel runs for minutes.
     const uint64_t max_samples_per_launch = 1ull << 31;
     uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
     int blocks_per_cu = 0;
@@ -672,8 +672,12 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         const uint32_t spp_l = std::min(spp_per_launch, p->spp - done);
         A.spp_first = p->spp_offset + done;
         A.spp_count = spp_l;
+        // A unit is ~2048 items (64 pixels x 32 samples, ~45 passes of the sphere scan): small enough that the waves
+        // finish within a percent of each other, large enough that the unit switch (one atomic, one tile flush) is
+        // noise.  Measured alternatives on configs[1]: 125-spp units +9 % time, 500-spp +30 %; a guided schedule of
+        // halving unit sizes cuts the accumulator traffic 6x but costs 4-6 % (heavy tiles finish late).
         A.spp_per_chunk = std::min(spp_l, kUnitSpp);
-        if (p->reserved) A.spp_per_chunk = std::min(spp_l, p->reserved);  // debug/test hook: force spp per chunk
+        if (p->reserved) A.spp_per_chunk = std::min(spp_l, p->reserved);  // debug/test hook: force spp per unit
         const uint32_t chunks = (spp_l + A.spp_per_chunk - 1) / A.spp_per_chunk;
         const uint64_t n_units = (uint64_t)A.n_tiles * chunks;
         if (n_units > 0xFFFFFFF0ull) return fail(c, RT_ERR_BAD_ARG, "too many work units in one launch");
