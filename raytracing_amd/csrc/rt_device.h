@@ -1,7 +1,7 @@
 // rt_device.h — gfx950 device code of the path-tracing hot path (included by rt_lib.hip only).
 //
-// Written for CDNA4 directly: 64-wide wavefronts, the sphere list broadcast out of LDS with
-// ds_read_b128 (all lanes one address: conflict-free), fp32 VALU for the N-sphere scan, f64 VALU
+// Written for CDNA4 directly: 64-wide wavefronts, two rays per lane in packed fp32, the sphere lists fetched with
+// scalar loads and used from SGPRs, fp32 VALU for the N-sphere scan, f64 VALU
 // for the one winning sphere per bounce, no MFMA (nothing here is a dense contraction).
 //
 // Reference behaviour restated (file:line in /root/reference/src):
@@ -161,19 +161,18 @@ __device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
 //   (take b + s) and both have the sign of b when outside (take b - s): this is shape.rs:53-61's
 //   "near root if in range else far root" with the range start folded into o'.
 //
-// How it is mapped to gfx950 (measured, tools/ubench*.hip):
-//  * A wave64 VALU instruction costs ~3.5-4 issue cycles whether or not its operands are SGPRs, and
+// How it is mapped to gfx950 (measured, tools/ubench*.hip; DESIGN.md section 4 has the numbers):
+//  * A wave64 VALU instruction issues in ~4.4 cycles whether or not its operands are SGPRs, and
 //    v_pk_{add,mul,fma}_f32 cost the same as their scalar forms while doing two lanes' worth: the 157 TF fp32
-//    peak exists only for packed math.  So EVERY LANE CARRIES TWO RAYS (A and B) and the ten
-//    arithmetic ops of a test are packed {A,B}: 53 -> 28 cycles per ray-test in the loop microbenchmark.
+//    peak exists only for packed math.  So EVERY LANE CARRIES TWO RAYS (A and B) and the ten arithmetic ops of a
+//    test up to disc are packed {A,B}.
 //  * The sphere is wave-uniform: it is fetched with SCALAR loads (s_load_dwordx16 = 4 spheres, constant
 //    address space, served by the scalar cache) and used straight from SGPRs, so the loop has no LDS or
 //    vector-memory instruction and holds no sphere in VGPRs.
 //  * f32 MFMA does not help: v_mfma_f32_32x32x2_f32 and VALU fp32 do NOT overlap on this part (65 + 38 cycles
 //    measured 106 together), they share the fp32 datapath.
-//  * v_sqrt_f32 (~8-10 cycles), v_bfi (copysign) and the final subtract are the un-packable tail.
-// The scan keeps only min(t') per ray (v_min3_u32: two spheres per instruction) and, per chunk of 8, which
-// chunk last lowered it; the sphere id is recovered once per bounce by re-testing that chunk.
+//  * v_sqrt_f32 (~8 cycles), v_bfi (copysign), the subtract and the min/select are un-packable: they run lazily,
+//    only for groups of spheres that some lane's line meets (see scan_spheres).
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) v4f* cv4p;  // constant address space => scalar loads
