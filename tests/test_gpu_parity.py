@@ -217,6 +217,26 @@ def test_render_properties_full_size(ctx, api):
         assert e.value.code == api.RT_ERR_BAD_ARG
 
 
+def test_work_unit_size_does_not_change_the_image(ctx, api):
+    """The persistent waves pull (tile, spp-chunk) units from a counter and switch units without draining (paths
+    of the old unit finish as orphans that add straight into the global sums). Whatever the unit size, which wave
+    ran a unit, or how many switches happened, the fixed-point sums - hence the image and the ray count - are
+    identical bit for bit. rt_params.reserved is the debug hook that forces the samples per unit."""
+    w = api.World("Random", seed=3, aspect=328 / 200)  # moving spheres + checker, ragged width (328 = 41 tiles)
+    ctx.upload(w.scene)
+    base = None
+    for unit in (0, 1, 7, 40, 1000):
+        p = api.make_params(328, 200, 40, seed=w.render_seed)
+        p.reserved = unit
+        img, st = ctx.render(w.camera, p)
+        if base is None:
+            base = (img, st.rays_traced)
+            assert np.isfinite(img).all() and st.samples == 328 * 200 * 40
+        else:
+            assert np.array_equal(img, base[0]), f"unit={unit}"
+            assert st.rays_traced == base[1], f"unit={unit}"
+
+
 def test_max_depth_semantics(ctx, api, orc):
     """main.rs:126-130: a path that still hits after max_depth bounces is black. TwoSpheres (camera between two
     huge checker spheres) keeps bouncing, so depth matters: compare a depth sweep against the oracle."""
