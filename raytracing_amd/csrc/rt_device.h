@@ -45,13 +45,16 @@ struct DevTexture {
 };
 
 // Device view of an uploaded scene.
-struct DevScene {
-    // fp32 scan lists (read with scalar loads: wave-uniform index)
+// fp32 scan lists (read with scalar loads: wave-uniform index)
+struct ScanLists {
     const float4* stat;   // ns_pad x {cx, cy, cz, -r^2}; pads have -r^2 = +1 at c = 0 (never hit)
     const float4* mov_a;  // nm_pad x {c0x, c0y, c0z, -r^2}
     const float4* mov_b;  // nm_pad x {dcx, dcy, dcz, 0}
-    const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
     int32_t ns_pad, nm_pad;
+};
+struct DevScene {
+    ScanLists lists;
+    const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
     // spheres too large for the fp32 scan (|c|,r >> 1: e.g. the r = 1000 ground): f64 test
     const int32_t* big_id;
     int32_t n_big;
@@ -65,6 +68,16 @@ struct DevScene {
     int32_t n_spheres;
     int32_t n_textures;
 };
+
+// Kernel arguments are re-read from the KERNARG segment (constant address space => scalar loads) at chosen points
+// instead of living in SGPRs for the whole kernel: see render_kernel.  `launder` makes the pointer opaque to the
+// optimiser, so loads through the result cannot be hoisted above that point.
+#define RT_AS4 __attribute__((address_space(4)))
+template <class T>
+__device__ __forceinline__ const RT_AS4 T* launder(const RT_AS4 T* p) {
+    asm volatile("" : "+s"(p));
+    return p;
+}
 
 // LDS image: only the noise tables (gathered per lane, 24 dependent lookups per noise call).  The sphere
 // lists are NOT staged in LDS: they are wave-uniform and go through the scalar cache into SGPRs (see the scan).
@@ -246,7 +259,7 @@ __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (
 // (disc >= 0 <=> sign bit clear; one v_max3_i32 per sphere folds the 2*kGroup sign bits, one compare and one
 // wave-uniform branch per group decide).  Upload orders the lists along a Morton curve so the spheres of a group
 // are neighbours and the groups a wave's rays meet are few.
-__device__ __forceinline__ void scan_spheres(const DevScene& S, const Pair& r, uint32_t& best_a, uint32_t& best_b,
+__device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, uint32_t& best_a, uint32_t& best_b,
                                              int& idx_a, int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
@@ -429,20 +442,27 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     return h;
 }
 
-// HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world.
+// HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
+// three steps so that a caller can re-read its scene arguments between them (render_kernel):
+//   closest_begin: f64 big-sphere pass + the scan frame;  scan_spheres;  closest_end: f64 decision + hit records.
 // do_a / do_b: whether that ray is live (a dead one still rides through the packed scan, its result is dropped).
-__device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
-                                             float t_min, HitRec& ha, HitRec& hb) {
+struct Hit2 {
     HitWork wa, wb;
-    uint32_t best_a = kInfBits, best_b = kInfBits;
-    wa.id_best = wb.id_best = -1;
-    wa.inv_len = wb.inv_len = 1.0f;
-    if (do_a) best_a = hit_begin(S, ra, t_min, wa);
-    if (do_b) best_b = hit_begin(S, rb, t_min, wb);
     Pair p;
-    p.dx = f2{ra.d.x * wa.inv_len, rb.d.x * wb.inv_len};
-    p.dy = f2{ra.d.y * wa.inv_len, rb.d.y * wb.inv_len};
-    p.dz = f2{ra.d.z * wa.inv_len, rb.d.z * wb.inv_len};
+    uint32_t best_a, best_b;
+    int slot_a, slot_b;
+};
+__device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                              float t_min, Hit2& x) {
+    x.best_a = x.best_b = kInfBits;
+    x.wa.id_best = x.wb.id_best = -1;
+    x.wa.inv_len = x.wb.inv_len = 1.0f;
+    if (do_a) x.best_a = hit_begin(S, ra, t_min, x.wa);
+    if (do_b) x.best_b = hit_begin(S, rb, t_min, x.wb);
+    Pair& p = x.p;
+    p.dx = f2{ra.d.x * x.wa.inv_len, rb.d.x * x.wb.inv_len};
+    p.dy = f2{ra.d.y * x.wa.inv_len, rb.d.y * x.wb.inv_len};
+    p.dz = f2{ra.d.z * x.wa.inv_len, rb.d.z * x.wb.inv_len};
     p.ox = f2{fmaf(t_min, ra.d.x, ra.o.x), fmaf(t_min, rb.d.x, rb.o.x)};
     p.oy = f2{fmaf(t_min, ra.d.y, ra.o.y), fmaf(t_min, rb.d.y, rb.o.y)};
     p.oz = f2{fmaf(t_min, ra.d.z, ra.o.z), fmaf(t_min, rb.d.z, rb.o.z)};
@@ -451,12 +471,21 @@ __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, c
     // sphere) so it never sends its wave into a root-extraction group
     if (!do_a) { p.dx.x = p.dy.x = p.dz.x = 0.0f; p.ox.x = 1e18f; p.oy.x = p.oz.x = 0.0f; p.time.x = 0.0f; }
     if (!do_b) { p.dx.y = p.dy.y = p.dz.y = 0.0f; p.ox.y = 1e18f; p.oy.y = p.oz.y = 0.0f; p.time.y = 0.0f; }
-    int slot_a = -1, slot_b = -1;
-    scan_spheres(S, p, best_a, best_b, slot_a, slot_b);
+    x.slot_a = x.slot_b = -1;
+}
+__device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                            float t_min, Hit2& x, HitRec& ha, HitRec& hb) {
     ha.sphere = -1;
     hb.sphere = -1;
-    if (do_a) ha = hit_end(S, ra, t_min, wa, best_a, slot_a);
-    if (do_b) hb = hit_end(S, rb, t_min, wb, best_b, slot_b);
+    if (do_a) ha = hit_end(S, ra, t_min, x.wa, x.best_a, x.slot_a);
+    if (do_b) hb = hit_end(S, rb, t_min, x.wb, x.best_b, x.slot_b);
+}
+__device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                             float t_min, HitRec& ha, HitRec& hb) {
+    Hit2 x;
+    closest_begin(S, ra, rb, do_a, do_b, t_min, x);
+    scan_spheres(S.lists, x.p, x.best_a, x.best_b, x.slot_a, x.slot_b);
+    closest_end(S, ra, rb, do_a, do_b, t_min, x, ha, hb);
 }
 
 // ------------------------------------------------------------------ textures
@@ -602,7 +631,8 @@ __device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables
 }
 
 // Camera::get_ray (screen.rs:79-94) with explicit uniforms.
-__device__ __forceinline__ Ray camera_ray(const rt_camera& c, float i, float j, float u0, float u1, float u2) {
+template <class CameraT>
+__device__ __forceinline__ Ray camera_ray(const CameraT& c, float i, float j, float u0, float u1, float u2) {
     f3 o = {c.origin[0], c.origin[1], c.origin[2]};
     if (c.lens_radius != 0.0f) {
         const f3 rd = map_unit_disk(u0, u1) * c.lens_radius;

@@ -67,14 +67,20 @@ struct PathState {
 #define RT_WAVES_PER_EU 3  // 154 VGPRs, no scratch.  2, 3 and 4 waves per SIMD measure within 2 % of each other, but 4
                            // (128 VGPRs) spills ~3 dwords per lane per pass = 17 GB of scratch writes per launch
 #endif
-__global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A) {
+__global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
+    // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
+    // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
+    // (refill) and the scan-list fields (scan) are re-read from the kernarg segment (constant address space =>
+    // one batch of scalar loads) where they are used; `launder` keeps the optimiser from hoisting those loads.
+    typedef const RT_AS4 RenderArgs* ArgsPtr;
+    const ArgsPtr K0 = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // A_kernarg is the only argument: offset 0
+    const RenderArgs& A = A_kernarg;
     extern __shared__ __align__(16) unsigned char lds[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const LdsScene L = stage_scene(A.S, lds, tid, kBlock);
     unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes) + wave * 192;  // wave-private
     acc[lane] = 0; acc[lane + 64] = 0; acc[lane + 128] = 0;
-    const float inv_w = 1.0f / ((float)A.W - 1.0f), inv_h = 1.0f / ((float)A.H - 1.0f);
 
     // current unit (wave-uniform)
     uint32_t tx0 = 0, ty0 = 0, tw = 1, npix = 0, s_lo = 0;
@@ -139,25 +145,26 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 if (item < total) {
+                    const ArgsPtr K = launder(K0);  // camera + image geometry: read here, not held across the pass
                     const uint32_t smp_i = item / npix;
                     P.pix_local = item - smp_i * npix;
                     const uint32_t ly = P.pix_local / tw, lx = P.pix_local - ly * tw;
                     const uint32_t x = tx0 + lx, y = ty0 + ly;
-                    P.pix = y * A.W + x;
-                    P.smp = A.spp_first + s_lo + smp_i;
+                    P.pix = y * K->W + x;
+                    P.smp = K->spp_first + s_lo + smp_i;
                     uint32_t r0[4];
-                    philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_PIXEL, 0u, r0);
-                    const float ri = A.antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
-                    const float rj = A.antialias ? u01(r0[1]) : 0.0f;
-                    const float ci = ((float)x + ri) * inv_w;           // main.rs:81
-                    const float cj = 1.0f - ((float)y + rj) * inv_h;    // main.rs:82
+                    philox4x32_10(K->k0, K->k1, P.pix, P.smp, DIM_PIXEL, 0u, r0);
+                    const float ri = K->antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
+                    const float rj = K->antialias ? u01(r0[1]) : 0.0f;
+                    const float ci = ((float)x + ri) * (1.0f / ((float)K->W - 1.0f));           // main.rs:81
+                    const float cj = 1.0f - ((float)y + rj) * (1.0f / ((float)K->H - 1.0f));    // main.rs:82
                     float ut = 0.0f;
-                    if (A.cam.has_shutter) {
+                    if (K->cam.has_shutter) {
                         uint32_t r1[4];
-                        philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_TIME, 0u, r1);
+                        philox4x32_10(K->k0, K->k1, P.pix, P.smp, DIM_TIME, 0u, r1);
                         ut = u01(r1[0]);
                     }
-                    P.ray = camera_ray(A.cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
+                    P.ray = camera_ray(K->cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
                     P.thr = {1.0f, 1.0f, 1.0f};
                     P.depth = 0;
                     P.alive = true;
@@ -173,7 +180,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
         // ---- one ray segment per live path: closest hit (both paths in one packed scan), then scatter
         HitRec h[2];
-        closest_hit2(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, h[0], h[1]);
+        {
+            Hit2 x;
+            closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
+            {
+                const ArgsPtr K = launder(K0);
+                ScanLists L;
+                L.stat = K->S.lists.stat; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
+                scan_spheres(L, x.p, x.best_a, x.best_b, x.slot_a, x.slot_b);
+            }
+            closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
+        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
@@ -589,9 +607,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     DevScene D{};
     int rc;
 #define UP(expr) if ((rc = (expr)) != RT_OK) { free_scene(c); return rc; }
-    UP(dev_copy(c, stat.data(), stat.size(), &D.stat));
-    UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.mov_a));
-    UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.mov_b));
+    UP(dev_copy(c, stat.data(), stat.size(), &D.lists.stat));
+    UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
+    UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
     UP(dev_copy(c, s->c0x, (size_t)s->n_spheres, &D.c0x));
@@ -607,8 +625,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
     UP(dev_copy(c, s->noise_tables, (size_t)s->n_noise_tables, &D.tables));
 #undef UP
-    D.ns_pad = (int32_t)stat.size();
-    D.nm_pad = (int32_t)mov_a.size();
+    D.lists.ns_pad = (int32_t)stat.size();
+    D.lists.nm_pad = (int32_t)mov_a.size();
     D.n_big = (int32_t)big_id.size();
     D.n_tables = (int32_t)s->n_noise_tables;
     D.n_spheres = (int32_t)s->n_spheres;

@@ -19,7 +19,7 @@ __global__ __launch_bounds__(256, W) void k(const DevScene S, float* out, int re
     for (int r = 0; r < reps; ++r) {
         uint32_t ba = kInfBits, bb = kInfBits;
         int sa = -1, sb = -1;
-        scan_spheres(S, p, ba, bb, sa, sb);
+        scan_spheres(S.lists, p, ba, bb, sa, sb);
         acc ^= ba ^ bb ^ (uint32_t)sa ^ (uint32_t)sb;
         p.ox.x += 1e-5f;
     }
@@ -47,7 +47,7 @@ int main() {
         DevScene S{};
         float4* d; CHECK(hipMalloc(&d, n * sizeof(float4)));
         CHECK(hipMemcpy(d, st.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        S.stat = d; S.ns_pad = n; S.nm_pad = 0; S.mov_a = d; S.mov_b = d;
+        S.lists.stat = d; S.lists.ns_pad = n; S.lists.nm_pad = 0; S.lists.mov_a = d; S.lists.mov_b = d;
         float* dout; CHECK(hipMalloc(&dout, 256 * 8 * 256 * sizeof(float)));
         run<1>(S, dout, n); run<2>(S, dout, n); run<3>(S, dout, n); run<4>(S, dout, n);
     }
