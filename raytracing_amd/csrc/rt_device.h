@@ -29,7 +29,7 @@ constexpr int kChunk = 8;           // scan lists are padded to a multiple of th
 #define RT_TAILCOND2 __builtin_amdgcn_ballot_w64(hit >= 0) != 0
 #endif
 #ifndef RT_TAILCOND
-#define RT_TAILCOND __builtin_amdgcn_ballot_w64(any >= 0) != 0
+#define RT_TAILCOND __builtin_expect(__builtin_amdgcn_ballot_w64(any >= 0) != 0, 0)
 #endif
 #ifndef RT_ASM_PREFETCH
 #define RT_ASM_PREFETCH 1
