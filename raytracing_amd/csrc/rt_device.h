@@ -564,6 +564,9 @@ __device__ inline float noise_eval(const DevTexture& T, const rt_noise_table* ta
     }
     return v;
 }
+// kNoise = false compiles the noise textures out: the render kernel is instantiated both ways and the scenes
+// without a noise texture (upload knows) run the variant whose register budget is not set by Perlin code.
+template <bool kNoise = true>
 __device__ inline f3 texture_value(const DevScene& S, const rt_noise_table* lds_tables, int tex_id, f3 p) {
     const DevTexture& T = S.texs[tex_id];
     const int kind = T.t.kind;
@@ -576,6 +579,7 @@ __device__ inline f3 texture_value(const DevScene& S, const rt_noise_table* lds_
         const float* c = parity ? T.t.color_a : T.t.color_b;
         return {c[0], c[1], c[2]};
     }
+    if (!kNoise) return {0.0f, 0.0f, 0.0f};  // unreachable: this variant is only launched for noise-free scenes
     const float v = noise_eval(T, lds_tables, p);
     return {v, v, v};
 }
@@ -594,6 +598,7 @@ __device__ __forceinline__ float schlick(float cosv, float eta) {  // material.r
 // Material::scatter with explicit uniforms u0,u1.  Returns the albedo; `r` becomes the scattered ray.
 // Lanes of a wave hold different materials, so the three branches usually all run: what they share (the unit
 // incident direction, the unit-sphere sample) is computed once outside them.
+template <bool kNoise = true>
 __device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables, const HitRec& h, Ray& r, float u0,
                              float u1) {
     const rt_material m = S.mats[S.mat_id[h.sphere]];
@@ -617,7 +622,7 @@ __device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables
         if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
             dir = h.n + sph;
             if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard (deviations)
-            albedo = texture_value(S, lds_tables, m.texture_id, h.p);
+            albedo = texture_value<kNoise>(S, lds_tables, m.texture_id, h.p);
         } else {  // material.rs:61-72
             const f3 fz = sph * m.fuzz;
             dir = reflect_unit(ud, h.n) + fz;

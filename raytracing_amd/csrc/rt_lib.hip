@@ -67,6 +67,7 @@ struct PathState {
 #define RT_WAVES_PER_EU 3  // 154 VGPRs, no scratch.  2, 3 and 4 waves per SIMD measure within 2 % of each other, but 4
                            // (128 VGPRs) spills ~3 dwords per lane per pass = 17 GB of scratch writes per launch
 #endif
+template <bool kNoise>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
     // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
     // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
@@ -205,7 +206,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 } else {
                     uint32_t rb[4];
                     philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_BOUNCE0 + P.depth, 0u, rb);
-                    const f3 albedo = scatter(A.S, L.tables, h[s], P.ray, u01(rb[0]), u01(rb[1]));
+                    const f3 albedo = scatter<kNoise>(A.S, L.tables, h[s], P.ray, u01(rb[0]), u01(rb[1]));
                     P.thr = P.thr * albedo;  // main.rs:118
                     ++P.depth;
                     if (P.depth == A.max_depth) done = true;  // main.rs:126-130: black
@@ -371,6 +372,7 @@ struct rt_ctx {
     float* out = nullptr;
     size_t out_cap = 0;
     int cu_count = 256;
+    bool has_noise = false;  // the uploaded scene references a value/Perlin noise texture
 };
 
 namespace {
@@ -633,6 +635,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     D.n_textures = (int32_t)s->n_textures;
     c->S = D;
     c->lds_scene = align16(lds_need);
+    c->has_noise = false;
+    for (uint32_t i = 0; i < s->n_textures; ++i) c->has_noise |= s->textures[i].kind >= RT_TEX_VALUE_NOISE;
     c->has_scene = true;
     return RT_OK;
 }
@@ -681,7 +685,9 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     const uint64_t max_samples_per_launch = 1ull << 31;
     uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
     int blocks_per_cu = 0;
-    RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel, kBlock, lds_bytes));
+    const bool noise = c->has_noise;  // noise-free scenes run the variant with the noise textures compiled out
+    RT_HIP(c, noise ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<true>, kBlock, lds_bytes)
+                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<false>, kBlock, lds_bytes));
     if (blocks_per_cu < 1) return fail(c, RT_ERR_HIP, "render kernel does not fit a compute unit");
     const uint32_t resident_blocks = (uint32_t)c->cu_count * (uint32_t)blocks_per_cu;
     uint32_t done = 0, launches = 0;
@@ -703,7 +709,8 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         A.unit_counter = reinterpret_cast<unsigned int*>(c->rays + 1);
         RT_HIP(c, hipMemsetAsync(c->rays + 1, 0, sizeof(unsigned long long), c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
-        hipLaunchKernelGGL(render_kernel, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
+        if (noise) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
+        else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
         done += spp_l;
         ++launches;

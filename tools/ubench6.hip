@@ -36,6 +36,24 @@ __global__ __launch_bounds__(256, W) void k(float* out, int iters, float s0, flo
         } else if (V == 7) {  // 2-deep dependent pk (alternating two chains)
             asm volatile(R8("v_pk_fma_f32 %0, %0, %5, %4\n v_pk_fma_f32 %1, %1, %5, %4\n v_pk_fma_f32 %0, %0, %5, %4\n v_pk_fma_f32 %1, %1, %5, %4\n")
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));
+        } else if (V == 9) {  // v_fma_f32 with SGPR addend, independent
+            asm volatile(R8("v_fma_f32 %0, %4, %5, %6\n v_fma_f32 %1, %4, %5, %6\n v_fma_f32 %2, %4, %5, %6\n v_fma_f32 %3, %4, %5, %6\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x), "s"(s0));
+        } else if (V == 10) {  // v_fma_f32 dependent chain
+            asm volatile(R8("v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %0, %0, %5, %4\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x));
+        } else if (V == 11) {  // v_sub_f32 SGPR - VGPR (VOP2), independent
+            asm volatile(R8("v_sub_f32 %0, %6, %4\n v_sub_f32 %1, %6, %5\n v_sub_f32 %2, %6, %4\n v_sub_f32 %3, %6, %5\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x), "s"(s0));
+        } else if (V == 12) {  // the scalar sphere test as the compiler would interleave it: 2 spheres, SGPR operands
+            asm volatile(R8("v_sub_f32 %0, %6, %4\n v_sub_f32 %1, %7, %4\n v_fma_f32 %2, %0, %0, %6\n v_fma_f32 %3, %1, %1, %7\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x), "s"(s0), "s"(s1));
+        } else if (V == 13) {  // two-deep dependent v_fma_f32 (two alternating chains)
+            asm volatile(R8("v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %1, %1, %5, %4\n v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %1, %1, %5, %4\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x));
+        } else if (V == 14) {  // four alternating chains
+            asm volatile(R8("v_fma_f32 %0, %0, %5, %4\n v_fma_f32 %1, %1, %5, %4\n v_fma_f32 %2, %2, %5, %4\n v_fma_f32 %3, %3, %5, %4\n")
+                         : "+v"(a.x), "+v"(b.x), "+v"(c.x), "+v"(d.x) : "v"(e.x), "v"(f.x));
         } else if (V == 8) {  // pk_mul vgpr*vgpr
             asm volatile(R8("v_pk_mul_f32 %0, %4, %5\n v_pk_mul_f32 %1, %4, %5\n v_pk_mul_f32 %2, %4, %5\n v_pk_mul_f32 %3, %4, %5\n")
                          : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(e), "v"(f));
@@ -56,7 +74,7 @@ void run(const char* name, float* dout) {
     printf("%-52s W=%d  cycles(2.4GHz)/instr/SIMD = %5.2f\n", name, W, ms * 1e-3 * 2.4e9 / ((double)iters * 32 * W));
     fflush(stdout);
 }
-#define RUNW(V, name) run<V, 1>(name, dout); run<V, 2>(name, dout); run<V, 4>(name, dout);
+#define RUNW(V, name) run<V, 1>(name, dout); run<V, 2>(name, dout); run<V, 4>(name, dout); run<V, 6>(name, dout); run<V, 8>(name, dout);
 int main() {
     float* dout; CHECK(hipMalloc(&dout, 256 * 8 * 256 * sizeof(float)));
     RUNW(6, "v_fma_f32 independent");
@@ -68,5 +86,11 @@ int main() {
     RUNW(3, "v_pk_fma_f32 dependent chain");
     RUNW(7, "v_pk_fma_f32 two alternating chains");
     RUNW(5, "v_max_i32 / v_max3_i32");
+    RUNW(9, "v_fma_f32 SGPR addend, independent");
+    RUNW(10, "v_fma_f32 dependent chain");
+    RUNW(13, "v_fma_f32 two alternating chains");
+    RUNW(14, "v_fma_f32 four alternating chains");
+    RUNW(11, "v_sub_f32 SGPR - VGPR");
+    RUNW(12, "v_sub/v_fma mix, SGPR operands");
     return 0;
 }
