@@ -237,6 +237,21 @@ def test_work_unit_size_does_not_change_the_image(ctx, api):
             assert st.rays_traced == base[1], f"unit={unit}"
 
 
+def test_multi_launch_render_matches_partition(ctx, api):
+    """A render of more than 2^31 samples is split into several kernel launches (each with its own unit queue).
+    2048 x 2048 @ 520 spp = 2.18e9 samples -> 2 launches; it must equal the two halves rendered separately with
+    spp_offset (the multi-GPU partition), and every pixel must have received exactly 520 samples."""
+    w = api.World("Balls", seed=1, aspect=1.0)
+    ctx.upload(w.scene)
+    W = H = 2048
+    full, st = ctx.render(w.camera, api.make_params(W, H, 520, max_depth=8, seed=9))
+    assert st.n_launches == 2 and st.samples == W * H * 520
+    lo, s0 = ctx.render(w.camera, api.make_params(W, H, 260, max_depth=8, seed=9))
+    hi, s1 = ctx.render(w.camera, api.make_params(W, H, 260, max_depth=8, seed=9, spp_offset=260))
+    assert s0.n_launches == 1 and s0.rays_traced + s1.rays_traced == st.rays_traced
+    assert np.abs((lo.astype(np.float64) + hi.astype(np.float64)) / 2 - full).max() < 2e-7
+
+
 def test_max_depth_semantics(ctx, api, orc):
     """main.rs:126-130: a path that still hits after max_depth bounces is black. TwoSpheres (camera between two
     huge checker spheres) keeps bouncing, so depth matters: compare a depth sweep against the oracle."""
