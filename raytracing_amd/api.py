@@ -229,6 +229,37 @@ class World:
             pass
 
 
+class FlatScene:
+    """A caller-built rt_scene (the Python twin of INTEGRATION.md's `FlatScene::as_rt_scene`): spheres in world order
+    as arrays, materials as (type, albedo, fuzz, ior, texture_id) tuples, textures as `Texture` structs. Keeps the
+    arrays alive for as long as `.scene` is used."""
+
+    def __init__(self, c0, radius, material_id, materials, textures=(), dc=None, noise_tables=()):
+        c0 = np.asarray(c0, np.float32).reshape(-1, 3)
+        n = c0.shape[0]
+        dc = np.zeros((n, 3), np.float32) if dc is None else np.asarray(dc, np.float32).reshape(n, 3)
+        self._cols = [np.ascontiguousarray(c0[:, k]) for k in range(3)] + \
+                     [np.ascontiguousarray(dc[:, k]) for k in range(3)]
+        self._radius = np.ascontiguousarray(radius, np.float32).reshape(n)
+        self._mid = np.ascontiguousarray(material_id, np.uint32).reshape(n)
+        self._mats = (Material * max(len(materials), 1))()
+        for i, (typ, albedo, fuzz, ior, tex) in enumerate(materials):
+            self._mats[i] = Material(int(typ), (C.c_float * 3)(*albedo), float(fuzz), float(ior), int(tex), 0)
+        self._texs = (Texture * max(len(textures), 1))(*textures)
+        self._tabs = (NoiseTable * max(len(noise_tables), 1))(*noise_tables)
+        ptr = lambda a: a.ctypes.data_as(f32p)
+        self.scene = Scene(n, *[ptr(a) for a in self._cols], ptr(self._radius), self._mid.ctypes.data_as(u32p),
+                           len(materials), self._mats, len(textures), self._texs, len(noise_tables), self._tabs)
+
+
+def solid_texture(rgb) -> Texture:
+    t = Texture()
+    t.kind = RT_TEX_SOLID
+    t.color_a = (C.c_float * 3)(*rgb)
+    t.color_b = (C.c_float * 3)(*rgb)
+    return t
+
+
 def camera_build(origin, look_at, view_up=None, vfov_degrees=60.0, aspect_ratio=1024 / 576, aperture=0.0,
                  focus_dist=0.0, shutter=None) -> Camera:
     """`CameraBuilder::build` (screen.rs:112-147)."""

@@ -481,13 +481,14 @@ void rt_destroy(rt_ctx* c) {
 int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     if (!c || !s) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     RT_HIP(c, hipSetDevice(c->device));
-    if (s->n_spheres == 0) return fail(c, RT_ERR_BAD_ARG, "scene has no spheres");
+    // n_spheres == 0 is a valid world (an empty HitList, hit.rs:100-110: every ray sees the sky)
     if (s->n_spheres > RT_MAX_SPHERES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_SPHERES spheres");
-    if (s->n_materials == 0 || s->n_materials > RT_MAX_MATERIALS) return fail(c, RT_ERR_BAD_ARG, "bad n_materials");
+    if ((s->n_spheres && s->n_materials == 0) || s->n_materials > RT_MAX_MATERIALS) return fail(c, RT_ERR_BAD_ARG, "bad n_materials");
     if (s->n_textures > RT_MAX_TEXTURES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_TEXTURES textures");
     if (s->n_noise_tables > RT_MAX_NOISE_TABLES) return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than RT_MAX_NOISE_TABLES noise tables");
-    if (!s->c0x || !s->c0y || !s->c0z || !s->dcx || !s->dcy || !s->dcz || !s->radius || !s->material_id || !s->materials)
+    if (s->n_spheres && (!s->c0x || !s->c0y || !s->c0z || !s->dcx || !s->dcy || !s->dcz || !s->radius || !s->material_id))
         return fail(c, RT_ERR_BAD_ARG, "NULL scene array");
+    if (s->n_materials && !s->materials) return fail(c, RT_ERR_BAD_ARG, "NULL scene array");
     if ((s->n_textures && !s->textures) || (s->n_noise_tables && !s->noise_tables))
         return fail(c, RT_ERR_BAD_ARG, "NULL texture / noise table array");
     for (uint32_t i = 0; i < s->n_materials; ++i) {

@@ -252,6 +252,61 @@ def test_multi_launch_render_matches_partition(ctx, api):
     assert np.abs((lo.astype(np.float64) + hi.astype(np.float64)) / 2 - full).max() < 2e-7
 
 
+def _random_flat_scene(api, n, seed, moving_every=0):
+    """n small spheres in a 40 x 6 x 40 box + a ground sphere, three material kinds; caller-built rt_scene."""
+    rng = np.random.default_rng(seed)
+    c0 = np.empty((n, 3), np.float32)
+    c0[:, 0] = rng.uniform(-20, 20, n); c0[:, 1] = rng.uniform(0.2, 6, n); c0[:, 2] = rng.uniform(-20, 20, n)
+    rad = rng.uniform(0.15, 0.45, n).astype(np.float32)
+    dc = np.zeros((n, 3), np.float32)
+    if moving_every:
+        dc[::moving_every, 1] = rng.uniform(0.05, 0.5, len(dc[::moving_every]))
+    c0[0] = (0, -1000, 0); rad[0] = 1000; dc[0] = 0
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_LAMBERTIAN, (0.7, 0.2, 0.2), 0, 0, 1),
+            (api.RT_MAT_METAL, (0.8, 0.8, 0.6), 0.1, 0, -1), (api.RT_MAT_DIELECTRIC, (1, 1, 1), 0, 1.5, -1)]
+    mid = rng.integers(1, 4, n).astype(np.uint32)
+    mid[0] = 0
+    texs = [api.solid_texture((0.5, 0.5, 0.5)), api.solid_texture((0.7, 0.2, 0.2))]
+    return api.FlatScene(c0, rad, mid, mats, texs, dc=dc)
+
+
+def test_empty_world_is_all_sky(ctx, api, orc):
+    """HitList with no objects (hit.rs:100-110 returns None): every ray misses, every sample is the sky gradient
+    (main.rs:133-138); one ray per sample."""
+    fs = api.FlatScene(np.zeros((0, 3)), np.zeros(0), np.zeros(0), [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0)],
+                       [api.solid_texture((0.5, 0.5, 0.5))])
+    ctx.upload(fs.scene)
+    cam = api.camera_build((0, 1, 5), (0, 0, 0), vfov_degrees=40.0, aspect_ratio=64 / 48)
+    rays = ctx.camera_rays(cam, np.random.default_rng(1).random((500, 2), dtype=np.float32), np.zeros((500, 4), np.float32))
+    assert not ctx.intersect_batch(rays)["hit"].any()
+    p = api.make_params(64, 48, 16, seed=5)
+    img, st = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER)
+    assert st.rays_traced == 64 * 48 * 16 == rays_ref
+    assert np.abs(img - ref).max() < 2e-6
+
+
+@pytest.mark.parametrize("n,moving_every", [(2048, 0), (2048, 3), (1, 0), (9, 2)])
+def test_caller_built_scenes_up_to_the_limit(ctx, api, orc, n, moving_every):
+    """Scenes that do not come from the scene factory: the 2048-sphere limit (static only, and a third of them
+    moving), a lone ground sphere, a list that needs padding.  Ray batches bit-exact / 1e-5 against the oracle,
+    a small render at path level."""
+    fs = _random_flat_scene(api, n, seed=n + moving_every, moving_every=moving_every)
+    ctx.upload(fs.scene)
+    cam = api.camera_build((26, 7, 9), (0, 1, 0), vfov_degrees=35.0, aspect_ratio=96 / 64, aperture=0.05,
+                           focus_dist=20.0, shutter=(0.0, 1.0) if moving_every else None)
+    rng = np.random.default_rng(7)
+    rays = ctx.camera_rays(cam, rng.random((4096, 2), dtype=np.float32), rng.random((4096, 4), dtype=np.float32))
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(fs.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
+    print(f"n={n} moving_every={moving_every}: {st}")
+    p = api.make_params(96, 64, 8, max_depth=12, seed=11)
+    img, s1 = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+
+
 def test_max_depth_semantics(ctx, api, orc):
     """main.rs:126-130: a path that still hits after max_depth bounces is black. TwoSpheres (camera between two
     huge checker spheres) keeps bouncing, so depth matters: compare a depth sweep against the oracle."""
