@@ -101,8 +101,11 @@ __device__ inline LdsScene stage_scene(const DevScene& S, unsigned char* lds, in
 // bit for bit and against the Random123 known-answer vectors.
 __device__ __forceinline__ void philox4x32_10(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t c2,
                                               uint32_t c3, uint32_t out[4]) {
+#ifndef RT_PHILOX_ROUNDS
+#define RT_PHILOX_ROUNDS 10  // anything else is a timing experiment, not Philox4x32-10
+#endif
 #pragma unroll
-    for (int r = 0; r < 10; ++r) {
+    for (int r = 0; r < RT_PHILOX_ROUNDS; ++r) {
         // one 32x32->64 multiply (v_mad_u64_u32) per product instead of a mul_hi + mul_lo pair
         const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
         c0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
