@@ -97,6 +97,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         ps[s].alive = ps[s].orphan = false;
     }
     unsigned long long n_rays = 0;
+    HitRec h[2];  // closest hits of the previous pass (consumed by the scatter at the top of the next one)
+    h[0].sphere = h[1].sphere = -1;
 
     // the unit's tile: LDS sums -> global accumulators, LDS cleared (the region is private to this wave)
     auto flush_tile = [&]() {
@@ -137,26 +139,39 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 total = 0;
             }
         }
-        // ---- refill dead path slots from the unit's items
+        // ---- per slot: a dead slot takes the unit's next item; then ONE Philox call serves whichever the slot needs,
+        // the camera sample of a fresh item (dim 0) or the scatter of the hit found in the previous pass
+        // (dim 2 + depth).  A wave pays for a call whenever any lane needs one, so merging the two call sites
+        // halves the Philox work per pass (it is half of everything outside the scan).
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
             const unsigned long long need = __ballot(!P.alive);
+            bool fresh = false;
+            uint32_t x = 0, y = 0;
             if (!P.alive) {
                 const uint32_t item = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(need >> 32),
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 if (item < total) {
-                    const ArgsPtr K = launder(K0);  // camera + image geometry: read here, not held across the pass
+                    const ArgsPtr K = launder(K0);
                     const uint32_t smp_i = item / npix;
                     P.pix_local = item - smp_i * npix;
                     const uint32_t ly = P.pix_local / tw, lx = P.pix_local - ly * tw;
-                    const uint32_t x = tx0 + lx, y = ty0 + ly;
+                    x = tx0 + lx; y = ty0 + ly;
                     P.pix = y * K->W + x;
                     P.smp = K->spp_first + s_lo + smp_i;
-                    uint32_t r0[4];
-                    philox4x32_10(K->k0, K->k1, P.pix, P.smp, DIM_PIXEL, 0u, r0);
-                    const float ri = K->antialias ? u01(r0[0]) : 0.0f;  // main.rs:76-80
-                    const float rj = K->antialias ? u01(r0[1]) : 0.0f;
+                    P.depth = 0;
+                    fresh = true;
+                }
+            }
+            next = min(next + (uint32_t)__popcll(need), total);
+            if (fresh || P.alive) {
+                const ArgsPtr K = launder(K0);  // camera + image geometry: read here, not held across the pass
+                uint32_t r[4];
+                philox4x32_10(K->k0, K->k1, P.pix, P.smp, fresh ? (uint32_t)DIM_PIXEL : DIM_BOUNCE0 + P.depth, 0u, r);
+                if (fresh) {
+                    const float ri = K->antialias ? u01(r[0]) : 0.0f;  // main.rs:76-80
+                    const float rj = K->antialias ? u01(r[1]) : 0.0f;
                     const float ci = ((float)x + ri) * (1.0f / ((float)K->W - 1.0f));           // main.rs:81
                     const float cj = 1.0f - ((float)y + rj) * (1.0f / ((float)K->H - 1.0f));    // main.rs:82
                     float ut = 0.0f;
@@ -165,22 +180,23 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                         philox4x32_10(K->k0, K->k1, P.pix, P.smp, DIM_TIME, 0u, r1);
                         ut = u01(r1[0]);
                     }
-                    P.ray = camera_ray(K->cam, ci, cj, u01(r0[2]), u01(r0[3]), ut);
+                    P.ray = camera_ray(K->cam, ci, cj, u01(r[2]), u01(r[3]), ut);
                     P.thr = {1.0f, 1.0f, 1.0f};
-                    P.depth = 0;
                     P.alive = true;
                     P.orphan = false;
+                } else {  // the path hit h[s] in the previous pass and goes on (main.rs:117-125)
+                    const f3 albedo = scatter<kNoise>(A.S, L.tables, h[s], P.ray, u01(r[0]), u01(r[1]));
+                    P.thr = P.thr * albedo;  // main.rs:118
+                    ++P.depth;
                 }
             }
-            next = min(next + (uint32_t)__popcll(need), total);
         }
         if (__ballot(ps[0].alive || ps[1].alive) == 0ull) {
             if (!more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
             continue;          // (next >= total here, so the next pass claims a unit or clears `more`)
         }
 
-        // ---- one ray segment per live path: closest hit (both paths in one packed scan), then scatter
-        HitRec h[2];
+        // ---- one ray segment per live path: closest hit (both paths in one packed scan)
         {
             Hit2 x;
             closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
@@ -193,26 +209,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             }
             closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
         }
+        // ---- paths that end here: the sky (main.rs:133-138) or the depth budget (main.rs:126-130: black, and the
+        // scatter whose ray would never be traced is skipped).  A path that stays alive scatters at the top of the
+        // next pass.
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
             if (P.alive) {
                 ++n_rays;
-                bool done = false;
-                f3 rad = {0, 0, 0};
-                if (h[s].sphere < 0) {  // main.rs:133-138
-                    rad = P.thr * sky(P.ray.d);
-                    done = true;
-                } else {
-                    uint32_t rb[4];
-                    philox4x32_10(A.k0, A.k1, P.pix, P.smp, DIM_BOUNCE0 + P.depth, 0u, rb);
-                    const f3 albedo = scatter<kNoise>(A.S, L.tables, h[s], P.ray, u01(rb[0]), u01(rb[1]));
-                    P.thr = P.thr * albedo;  // main.rs:118
-                    ++P.depth;
-                    if (P.depth == A.max_depth) done = true;  // main.rs:126-130: black
-                }
-                if (done) {
+                if (h[s].sphere < 0) {
                     P.alive = false;
+                    const f3 rad = P.thr * sky(P.ray.d);
                     const float c[3] = {rad.x, rad.y, rad.z};
 #pragma unroll
                     for (int k = 0; k < 3; ++k) {
@@ -224,6 +231,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                             else atomicAdd(&acc[P.pix_local * 3 + k], q);
                         }
                     }
+                } else if (P.depth + 1 == A.max_depth) {
+                    P.alive = false;
                 }
             }
         }
