@@ -41,7 +41,8 @@ constexpr float kTwoPow32 = 4294967296.0f;
 struct DevTexture {
     rt_texture t;
     float fractal_max;  // (1 - gain^layers) / (1 - gain), material.rs:189,216 (computed in f64 on upload)
-    int32_t pad[3];
+    float freq_turns;   // freq / 2pi (computed in f64 on upload): the checker needs only the SIGN of sin(freq * x)
+    int32_t pad[2];
 };
 
 // Device view of an uploaded scene.
@@ -575,10 +576,12 @@ __device__ inline f3 texture_value(const DevScene& S, const rt_noise_table* lds_
     const int kind = T.t.kind;
     if (kind == RT_TEX_SOLID) return {T.t.color_a[0], T.t.color_a[1], T.t.color_a[2]};
     if (kind == RT_TEX_CHECKER) {  // material.rs:155-165
-        const float f = T.t.freq;
-        bool parity = sinf(p.x * f) < 0.0f;
-        parity ^= sinf(p.y * f) < 0.0f;
-        parity ^= sinf(p.z * f) < 0.0f;
+        // sin(f x) < 0  <=>  fract(f x / 2pi) > 1/2 : one multiply and v_fract_f32 per axis instead of three libm
+        // sinf (range reduction + polynomial); the argument f*x is no better known in fp32 than this phase is
+        const float ft = T.freq_turns;
+        bool parity = __builtin_amdgcn_fractf(p.x * ft) > 0.5f;
+        parity ^= __builtin_amdgcn_fractf(p.y * ft) > 0.5f;
+        parity ^= __builtin_amdgcn_fractf(p.z * ft) > 0.5f;
         const float* c = parity ? T.t.color_a : T.t.color_b;
         return {c[0], c[1], c[2]};
     }

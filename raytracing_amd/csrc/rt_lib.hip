@@ -513,6 +513,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         if (t.kind < RT_TEX_SOLID || t.kind > RT_TEX_PERLIN_NOISE) return fail(c, RT_ERR_BAD_ARG, "unknown texture kind");
         texs[i].t = t;
         texs[i].fractal_max = 1.0f;
+        texs[i].freq_turns = (float)((double)t.freq / 6.283185307179586476925);
         if (t.kind >= RT_TEX_VALUE_NOISE) {
             if (t.table_id < 0 || (uint32_t)t.table_id >= s->n_noise_tables) return fail(c, RT_ERR_BAD_ARG, "noise table_id out of range");
             if (t.op < RT_NOISE_PLAIN || t.op > RT_NOISE_TURBULENCE) return fail(c, RT_ERR_BAD_ARG, "unknown noise op");
