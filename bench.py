@@ -52,15 +52,24 @@ def main():
     if args.gpus != world_size:
         if world_size == 1 and args.gpus > 1:
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    # RTX_BENCH_BACKEND=gloo is a REHEARSAL switch for boxes with fewer GPUs than ranks (ranks then share GPUs and
+    # the reduce goes through host memory): it exercises this file's multi-rank path, it is not a measurement.
+    backend = os.environ.get("RTX_BENCH_BACKEND", "nccl")
     dist = None
+    if backend != "nccl":
+        local_rank = local_rank % max(torch.cuda.device_count(), 1)
     if world_size > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # RCCL over xGMI
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
 
     ctx = api.Context(local_rank)  # raises if the HIP library or the device is missing: no fallback
     world = api.World(args.scene, seed=1, aspect=args.width / args.height)
@@ -78,7 +87,13 @@ def main():
     def step():
         st = ctx.render_accum_device(world.camera, params, acc.data_ptr())  # synchronous on the ctx stream
         if dist is not None:
-            dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+            if backend == "nccl":
+                dist.reduce(acc, dst=0, op=dist.ReduceOp.SUM)  # RCCL over xGMI
+                # the library renders on its own stream: the reduce must have read `acc` before the next step's
+                # render overwrites it, and a step is only done when its image is on rank 0
+                torch.cuda.synchronize()
+            else:
+                dist.reduce(acc.cpu(), dst=0, op=dist.ReduceOp.SUM)
         return st
 
     def fence():
@@ -95,7 +110,7 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
@@ -103,7 +118,7 @@ def main():
     rays = sum(int(s.rays_traced) for s in stats)
     kernel_ms = sum(float(s.kernel_ms) for s in stats)
     launches = sum(int(s.n_launches) for s in stats)
-    rays_all = torch.tensor([float(rays)], dtype=torch.float64, device=dev)
+    rays_all = torch.tensor([float(rays)], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(rays_all, op=dist.ReduceOp.SUM)
     rays_total = float(rays_all.item())
@@ -130,7 +145,7 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if backend == "nccl" else f"synthetic (REHEARSAL: backend {backend}, ranks may share a GPU)",
             "config": {
                 "workload": f"configs[1]: RTIOW final scene (static, {n_static + n_moving} spheres) "
                             f"{args.width}x{args.height} @ {args.spp} spp per GPU, max_depth {args.max_depth}, "
