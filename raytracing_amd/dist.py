@@ -33,4 +33,9 @@ def render_and_reduce(render_sum: Callable[[int, int], "object"], first: int, co
     acc = render_sum(first, count)
     if dist is not None and dist.is_initialized() and dist.get_world_size() > 1:
         dist.reduce(acc, dst=dst, op=dist.ReduceOp.SUM)
+        if getattr(acc, "is_cuda", False):
+            # the library renders on its own HIP stream, which is not ordered against torch's NCCL stream: wait
+            # for the collective on the host before the caller can render into (or read) this buffer again
+            import torch
+            torch.cuda.synchronize(acc.device)
     return acc
