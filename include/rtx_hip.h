@@ -27,10 +27,12 @@ extern "C" {
 
 #define RT_ABI_VERSION 1
 
-/* Limits of the LDS-staged scene (sphere list + noise tables <= 64 KiB of LDS). */
-#define RT_MAX_SPHERES 2048
-#define RT_MAX_MATERIALS 4096
-#define RT_MAX_TEXTURES 4096
+/* Limits.  The sphere lists are streamed through the scalar cache (not LDS), so the sphere limit is a sanity bound
+ * on a brute-force scan (cost per ray segment is linear in it), not a capacity: every reference scene has < 500.
+ * Noise tables (2 KiB each) are staged in LDS. */
+#define RT_MAX_SPHERES 16384
+#define RT_MAX_MATERIALS 16384
+#define RT_MAX_TEXTURES 16384
 #define RT_MAX_NOISE_TABLES 4
 
 typedef enum rt_status {

@@ -613,7 +613,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
     const size_t lds_need = lds_scene_bytes((int)s->n_noise_tables);
-    if ((stat.size() + 2 * mov_a.size()) * 16 > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "sphere lists exceed 64 KiB");
     if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
 
     free_scene(c);

@@ -4,7 +4,7 @@ the fp32 radiance-sum accumulators are summed onto rank 0 with ONE collective â€
 which is RCCL over xGMI with backend "nccl" on ROCm (and gloo in the CPU tests).
 
 The reference has no distributed path (it is shared-memory rayon, main.rs:64-67); this is the exchange step
-north_star adds. No other collective is used: the scene (<= 64 KiB) is replicated by construction.
+north_star adds. No other collective is used: the scene (a few hundred KiB at most) is replicated by construction.
 """
 from __future__ import annotations
 

@@ -286,10 +286,10 @@ def test_empty_world_is_all_sky(ctx, api, orc):
     assert np.abs(img - ref).max() < 2e-6
 
 
-@pytest.mark.parametrize("n,moving_every", [(2048, 0), (2048, 3), (1, 0), (9, 2)])
+@pytest.mark.parametrize("n,moving_every", [(16384, 0), (2048, 3), (1, 0), (9, 2)])
 def test_caller_built_scenes_up_to_the_limit(ctx, api, orc, n, moving_every):
-    """Scenes that do not come from the scene factory: the 2048-sphere limit (static only, and a third of them
-    moving), a lone ground sphere, a list that needs padding.  Ray batches bit-exact / 1e-5 against the oracle,
+    """Scenes that do not come from the scene factory: the 16384-sphere limit (static), 2048 with a third of them
+    moving, a lone ground sphere, a list that needs padding.  Ray batches bit-exact / 1e-5 against the oracle,
     a small render at path level."""
     fs = _random_flat_scene(api, n, seed=n + moving_every, moving_every=moving_every)
     ctx.upload(fs.scene)
@@ -329,7 +329,7 @@ def test_upload_validation(api):
     w = api.World("Balls", seed=1)
     s = w.scene
     keep = s.n_spheres
-    s.n_spheres = api.C.c_uint32(5000)
+    s.n_spheres = api.C.c_uint32(20000)
     with pytest.raises(api.RtError) as e:
         c.upload(s)
     assert e.value.code == api.RT_ERR_SCENE_TOO_LARGE
