@@ -64,8 +64,8 @@ struct PathState {
 };
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 3  // 154 VGPRs, no scratch.  2, 3 and 4 waves per SIMD measure within 2 % of each other, but 4
-                           // (128 VGPRs) spills ~3 dwords per lane per pass = 17 GB of scratch writes per launch
+#define RT_WAVES_PER_EU 3  // ~144 VGPRs, no scratch.  4 waves per SIMD (128 VGPRs) measure +2 % but spill 22 dwords per
+                           // lane, i.e. tens of GB of scratch writes per launch; 2 waves measure -1 %
 #endif
 template <bool kNoise>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
