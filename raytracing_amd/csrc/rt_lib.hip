@@ -25,7 +25,9 @@ namespace {
 constexpr int kBlock = 256;          // 4 waves per workgroup share one LDS copy of the scene
 constexpr int kWavesPerBlock = kBlock / 64;
 constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
-constexpr uint32_t kUnitSpp = 32;    // samples per pixel of one work unit (8x8 pixels x 32 spp = 2048 items, ~45 scan passes)
+// Work units are 8x8 pixels x kUnitSppA samples (3072 items, ~65 scan passes), except for the last kTailSpan (or
+// 1/8 of the) samples of a launch, which are cut into kUnitSppB-sample units so that the waves finish together.
+constexpr uint32_t kUnitSppA = 48, kUnitSppB = 8, kTailSpan = 128;
 constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
 constexpr float kBigCenter = 500.0f;
 
@@ -35,7 +37,7 @@ struct RenderArgs {
     uint32_t W, H, tiles_x, n_tiles;
     uint32_t spp_first;      // absolute index of this launch's first sample
     uint32_t spp_count;      // samples per pixel in this launch
-    uint32_t spp_per_chunk;  // chunk k covers samples [k*spp_per_chunk, ...) of them
+    uint32_t spp_a, n_a, spp_b;  // chunk k < n_a covers samples [k*spp_a, (k+1)*spp_a); later chunks are spp_b wide
     uint32_t n_units;        // work units of this launch = n_tiles * chunks; unit u = (tile u % n_tiles, chunk u / n_tiles)
     uint32_t max_depth;
     int32_t antialias;
@@ -131,8 +133,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 ty0 = (tile / A.tiles_x) * kTile;
                 tw = min((uint32_t)kTile, A.W - tx0);
                 npix = tw * min((uint32_t)kTile, A.H - ty0);
-                s_lo = chunk * A.spp_per_chunk;
-                total = npix * min(A.spp_per_chunk, A.spp_count - s_lo);
+                const bool big = chunk < A.n_a;
+                s_lo = big ? chunk * A.spp_a : A.n_a * A.spp_a + (chunk - A.n_a) * A.spp_b;
+                total = npix * (big ? A.spp_a : min(A.spp_b, A.spp_count - s_lo));
             } else {
                 more = false;
                 npix = 0;
@@ -706,13 +709,21 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         const uint32_t spp_l = std::min(spp_per_launch, p->spp - done);
         A.spp_first = p->spp_offset + done;
         A.spp_count = spp_l;
-        // A unit is ~2048 items (64 pixels x 32 samples, ~45 passes of the sphere scan): small enough that the waves
-        // finish within a percent of each other, large enough that the unit switch (one atomic, one tile flush) is
-        // noise.  Measured alternatives on configs[1]: 125-spp units +9 % time, 500-spp +30 %; a guided schedule of
-        // halving unit sizes cuts the accumulator traffic 6x but costs 4-6 % (heavy tiles finish late).
-        A.spp_per_chunk = std::min(spp_l, kUnitSpp);
-        if (p->reserved) A.spp_per_chunk = std::min(spp_l, p->reserved);  // debug/test hook: force spp per unit
-        const uint32_t chunks = (spp_l + A.spp_per_chunk - 1) / A.spp_per_chunk;
+        // Unit sizes (see kUnitSppA): chunk-major unit order means the small units are the last ones claimed.
+        // Measured on configs[1] (tools/unit_sweep.sh): uniform 16 / 24 / 32-spp units 262.6 / 264.6 / 266.5 ms,
+        // 125 spp +9 %, 500 spp +30 % (tiles differ 3x in cost, so the end-of-launch spread is several units);
+        // 48-spp units with a 128-spp tail of 8-spp units 261.8 ms, 40/8/96 260.6 ms, 64/8/64 269 ms; a schedule of
+        // halving sizes cut the accumulator traffic 6x but cost 4-6 %.
+        uint32_t ua = kUnitSppA, ub = kUnitSppB, span = std::max(kTailSpan, spp_l / 8);
+        if (const char* e = std::getenv("RTX_UNIT_A")) ua = std::max(1, std::atoi(e));        // tuning knobs
+        if (const char* e = std::getenv("RTX_UNIT_B")) ub = std::max(1, std::atoi(e));
+        if (const char* e = std::getenv("RTX_TAIL_SPAN")) span = (uint32_t)std::max(0, std::atoi(e));
+        if (p->reserved) { ua = ub = p->reserved; span = 0; }  // debug/test hook: force spp per unit
+        span = std::min(span, spp_l);
+        A.spp_a = ua; A.spp_b = ub;
+        A.n_a = (spp_l - span) / ua;
+        const uint32_t rest = spp_l - A.n_a * ua;
+        const uint32_t chunks = A.n_a + (rest + ub - 1) / ub;
         const uint64_t n_units = (uint64_t)A.n_tiles * chunks;
         if (n_units > 0xFFFFFFF0ull) return fail(c, RT_ERR_BAD_ARG, "too many work units in one launch");
         A.n_units = (uint32_t)n_units;
