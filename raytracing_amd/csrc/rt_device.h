@@ -195,7 +195,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) v4f* cv4p;  // constant address space => scalar loads
 __device__ __forceinline__ cv4p as_scalar(const float4* p) { return (cv4p)(uintptr_t)p; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
-__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return min(a, min(b, c)); }
 
 // the two rays of a lane, in the scan frame (component-wise pairs {A, B})
 struct Pair {
@@ -218,7 +217,8 @@ __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b,
     q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
 }
 // Root extraction for one ray of one sphere whose line test passed somewhere in the wave.  Strict <: the
-// first sphere in list order keeps a tie (hit.rs:100-110 narrows t_max with a half-open range).
+// first sphere in list order keeps a tie (hit.rs:100-110 narrows t_max with a half-open range; the lists are
+// stably sorted, so coincident spheres keep their world order).
 __device__ __forceinline__ void take_root(float b, float q, float disc, int slot, uint32_t& best, int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
     const uint32_t key = __float_as_uint(b - __builtin_copysignf(s, q));
