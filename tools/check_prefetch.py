@@ -3,9 +3,11 @@
 
 The next sphere group is fetched with an inline-asm `s_load_dwordx16 ... ; PF_LOAD` whose completion the
 compiler does not track; the matching `s_waitcnt lgkmcnt(0) ; PF_WAIT` is the first point where the destination
-SGPRs may be read.  This script reads the kernel ISA (make -C raytracing_amd/csrc asm -> rt_lib.s) and fails if
-any instruction between a PF_LOAD and the next PF_WAIT names one of the destination SGPRs (a copy or spill the
-register allocator might have inserted would read them before the data has arrived)."""
+SGPRs may be touched.  This script reads the kernel ISA (the Makefile emits rt_lib.s), builds the control-flow
+graph of every function (labels, s_branch / s_cbranch_* targets, fall-through) and walks it forward from each
+PF_LOAD: on every path, no instruction may name one of the destination SGPRs before a PF_WAIT is reached (a copy
+or spill inserted by the register allocator, or a temporary allocated on top of them, would read or clobber them
+while the data is still in flight), and no path may reach the end of the program without a PF_WAIT."""
 import re
 import sys
 
@@ -14,35 +16,76 @@ def sregs(text):
     out = set()
     for m in re.finditer(r"\bs\[(\d+):(\d+)\]", text):
         out.update(range(int(m.group(1)), int(m.group(2)) + 1))
-    for m in re.finditer(r"\bs(\d+)\b", text):
+    for m in re.finditer(r"(?<![\w\[:])s(\d+)\b", text):
         out.add(int(m.group(1)))
     return out
 
 
 def check(path):
-    lines = open(path).read().splitlines()
+    raw = open(path).read().splitlines()
+    # instruction list: (line number, code text, full text)
+    ins, label_at = [], {}
+    for no, ln in enumerate(raw, 1):
+        code = ln.split(";")[0].strip()
+        m = re.match(r"^([.\w$]+):", code)
+        if m:
+            label_at[m.group(1)] = len(ins)  # index of the next instruction
+            continue
+        if not code or code.startswith("."):
+            if "PF_" not in ln:
+                continue
+        if code.startswith(";") or not code:
+            continue
+        ins.append((no, code, ln))
     n_loads, bad = 0, []
-    i = 0
-    while i < len(lines):
-        ln = lines[i]
-        if "PF_LOAD" in ln and "s_load_dwordx16" in ln:
-            n_loads += 1
-            m = re.search(r"s_load_dwordx16\s+s\[(\d+):(\d+)\]", ln)
-            dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
-            j = i + 1
-            while j < len(lines) and "PF_WAIT" not in lines[j]:
-                code = lines[j].split(";")[0]
-                if code.strip() and not code.strip().endswith(":") and not code.strip().startswith("."):
-                    if "s_endpgm" in code:
-                        bad.append((i + 1, j + 1, "kernel ends before PF_WAIT"))
-                        break
-                    hit = sregs(code) & dst
-                    if hit:
-                        bad.append((i + 1, j + 1, "reads/writes s%s before PF_WAIT: %s" % (sorted(hit), code.strip())))
-                j += 1
-            if j == len(lines):
-                bad.append((i + 1, j, "no PF_WAIT after PF_LOAD"))
-        i += 1
+
+    def successors(i):
+        code = ins[i][1]
+        op = code.split()[0]
+        if op == "s_endpgm":
+            return []
+        if op == "s_branch":
+            t = code.split()[1]
+            return [label_at[t]] if t in label_at else []
+        if op.startswith("s_cbranch"):
+            t = code.split()[-1]
+            out = [i + 1] if i + 1 < len(ins) else []
+            if t in label_at:
+                out.append(label_at[t])
+            return out
+        if op in ("s_setpc_b64", "s_swappc_b64"):
+            return [None]  # indirect: cannot be followed
+        return [i + 1] if i + 1 < len(ins) else []
+
+    for i, (no, code, full) in enumerate(ins):
+        if "PF_LOAD" not in full or not code.startswith("s_load_dwordx16"):
+            continue
+        n_loads += 1
+        m = re.search(r"s_load_dwordx16\s+s\[(\d+):(\d+)\]", code)
+        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        seen, stack = set(), [j for j in successors(i)]
+        while stack:
+            j = stack.pop()
+            if j is None:
+                bad.append((no, no, "indirect branch between PF_LOAD and PF_WAIT"))
+                continue
+            if j in seen or j >= len(ins):
+                continue
+            seen.add(j)
+            jno, jcode, jfull = ins[j]
+            if "PF_WAIT" in jfull:
+                continue  # this path is safe from here on
+            if jcode.split()[0] == "s_endpgm":
+                bad.append((no, jno, "program ends before PF_WAIT"))
+                continue
+            if "PF_LOAD" in jfull:  # the sibling load of a two-load asm (or the next prefetch): its own walk checks it
+                hit = sregs(jcode.split(",")[0]) & dst
+            else:
+                hit = sregs(jcode) & dst
+            if hit:
+                bad.append((no, jno, "touches s%s before PF_WAIT: %s" % (sorted(hit), jcode)))
+                continue
+            stack.extend(successors(j))
     return n_loads, bad
 
 
@@ -52,7 +95,7 @@ if __name__ == "__main__":
     if n == 0:
         print("check_prefetch: no PF_LOAD found in", path)
         sys.exit(1)
-    for b in bad:
-        print("check_prefetch: line %d..%d: %s" % b)
+    for b in bad[:40]:
+        print("check_prefetch: load at line %d, line %d: %s" % b)
     print("check_prefetch: %d prefetch loads, %d violations" % (n, len(bad)))
     sys.exit(1 if bad else 0)
