@@ -60,6 +60,29 @@ def test_intersect_batches(ctx, api, name, case):
     assert not got["t"][miss].any() and not got["normal"][miss].any()  # a miss is all zeros
 
 
+@pytest.mark.parametrize("name", ["FinalStatic", "Random"])
+def test_intersect_large_incoherent_batch(ctx, api, orc, name):
+    """A quarter of a million rays against the live oracle: camera rays plus rays from random points in the scene
+    volume in random directions (what a wave sees after the first bounce: no coherence at all).  Same bar as the
+    fixed batches: ids and flags bit-exact outside the fp32 decision band, t / point / normal within 1e-5."""
+    w = api.World(name, seed=1, aspect=1200 / 800)
+    ctx.upload(w.scene)
+    rng = np.random.default_rng(2024)
+    n = 131072
+    cam = ctx.camera_rays(w.camera, rng.random((n, 2), dtype=np.float32), rng.random((n, 4), dtype=np.float32))
+    rnd = np.zeros(n, api.ray_dtype)
+    rnd["origin"] = np.stack([rng.uniform(-12, 12, n), rng.uniform(0.0, 3.0, n), rng.uniform(-12, 12, n)], 1)
+    d = rng.normal(size=(n, 3))
+    rnd["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))  # not normalised, as the reference
+    rnd["time"] = rng.random(n)
+    rays = np.concatenate([cam, rnd])
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(w.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.01)
+    print(name, st, "hits", int(exp["hit"].sum()))
+    assert exp["hit"].sum() > 0.5 * len(rays)
+
+
 def test_intersect_edge_cases(ctx, api, orc):
     w = api.World("Balls", seed=1)
     ctx.upload(w.scene)
