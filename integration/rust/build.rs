@@ -1,0 +1,29 @@
+// build.rs — UNVERIFIED (no Rust toolchain in the build image).  Builds librtx_hip.so from this repo's sources with
+// hipcc, or links a prebuilt one when RTX_HIP_PREBUILT points at the directory that holds it.
+use std::{env, path::PathBuf, process::Command};
+
+fn main() {
+    let out = PathBuf::from(env::var("OUT_DIR").unwrap());
+    let lib_dir = if let Ok(dir) = env::var("RTX_HIP_PREBUILT") {
+        PathBuf::from(dir) // e.g. <repo>/raytracing_amd (built and ISA-checked by its Makefile)
+    } else {
+        let root = PathBuf::from(env::var("RTX_HIP_ROOT").expect("RTX_HIP_ROOT = path to the rtx_hip repo"));
+        let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
+        let status = Command::new(hipcc)
+            // -ffp-contract=off is REQUIRED: a sample must not depend on which of a lane's two path slots ran it.
+            .args(["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-o"])
+            .arg(out.join("librtx_hip.so"))
+            .arg(root.join("raytracing_amd/csrc/rt_lib.hip"))
+            .arg(root.join("raytracing_amd/csrc/host_scene.cpp"))
+            .status()
+            .expect("running hipcc");
+        assert!(status.success(), "hipcc failed");
+        println!("cargo:rerun-if-changed={}", root.join("include/rtx_hip.h").display());
+        println!("cargo:rerun-if-changed={}", root.join("raytracing_amd/csrc/rt_lib.hip").display());
+        println!("cargo:rerun-if-changed={}", root.join("raytracing_amd/csrc/rt_device.h").display());
+        out
+    };
+    println!("cargo:rustc-link-search=native={}", lib_dir.display());
+    println!("cargo:rustc-link-lib=dylib=rtx_hip");
+    println!("cargo:rustc-link-arg=-Wl,-rpath,{}", lib_dir.display());
+}

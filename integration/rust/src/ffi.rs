@@ -1,0 +1,135 @@
+//! ffi.rs — `#[repr(C)]` mirror of include/rtx_hip.h (ABI version 1).  UNVERIFIED: no Rust toolchain in the build
+//! image; field order and types follow the header line by line.
+#![allow(non_camel_case_types, dead_code)]
+use std::os::raw::{c_char, c_int};
+
+pub const RT_OK: c_int = 0;
+pub const RT_ERR_BAD_ARG: c_int = -1;
+pub const RT_ERR_HIP: c_int = -2;
+pub const RT_ERR_SCENE_TOO_LARGE: c_int = -3;
+
+pub const RT_MAT_LAMBERTIAN: i32 = 0;
+pub const RT_MAT_METAL: i32 = 1;
+pub const RT_MAT_DIELECTRIC: i32 = 2;
+pub const RT_TEX_SOLID: i32 = 0;
+pub const RT_TEX_CHECKER: i32 = 1;
+pub const RT_TEX_VALUE_NOISE: i32 = 2;
+pub const RT_TEX_PERLIN_NOISE: i32 = 3;
+pub const RT_NOISE_PLAIN: i32 = 0;
+pub const RT_NOISE_FBM: i32 = 1;
+pub const RT_NOISE_TURBULENCE: i32 = 2;
+
+#[repr(C)]
+pub struct rt_ctx {
+    _private: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy)]
+pub struct rt_noise_table {
+    pub perms: [u16; 512],
+    pub randoms: [f32; 256],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_texture {
+    pub kind: i32,
+    pub color_a: [f32; 3], // solid colour / checker `odd`
+    pub color_b: [f32; 3], // checker `even`
+    pub freq: f32,
+    pub op: i32,
+    pub lacunarity: f32,
+    pub gain: f32,
+    pub layers: i32,
+    pub marbled: i32,
+    pub sin_freq: f32,
+    pub phase: f32,
+    pub marble_gain: f32, // freq * noise_gain (material.rs:251)
+    pub table_id: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_material {
+    pub type_: i32,
+    pub albedo: [f32; 3],
+    pub fuzz: f32,
+    pub ior: f32,
+    pub texture_id: i32,
+    pub reserved: i32,
+}
+
+#[repr(C)]
+pub struct rt_scene {
+    pub n_spheres: u32,
+    pub c0x: *const f32,
+    pub c0y: *const f32,
+    pub c0z: *const f32,
+    pub dcx: *const f32,
+    pub dcy: *const f32,
+    pub dcz: *const f32,
+    pub radius: *const f32,
+    pub material_id: *const u32,
+    pub n_materials: u32,
+    pub materials: *const rt_material,
+    pub n_textures: u32,
+    pub textures: *const rt_texture,
+    pub n_noise_tables: u32,
+    pub noise_tables: *const rt_noise_table,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_camera {
+    pub origin: [f32; 3],
+    pub lower_left: [f32; 3],
+    pub horiz: [f32; 3],
+    pub vert: [f32; 3],
+    pub u: [f32; 3],
+    pub v: [f32; 3],
+    pub lens_radius: f32,
+    pub shutter_open: f32,
+    pub shutter_close: f32,
+    pub has_shutter: i32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_params {
+    pub width: u32,
+    pub height: u32,
+    pub spp: u32,
+    pub max_depth: u32,
+    pub antialias: i32,
+    pub spp_offset: u32,
+    pub seed: u64,
+    pub t_min: f32,
+    pub reserved: u32,
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_stats {
+    pub rays_traced: u64,
+    pub samples: u64,
+    pub kernel_ms: f32,
+    pub total_ms: f32,
+    pub n_launches: u32,
+    pub reserved: u32,
+}
+
+extern "C" {
+    pub fn rt_abi_version() -> c_int;
+    pub fn rt_create(device: c_int, out: *mut *mut rt_ctx) -> c_int;
+    pub fn rt_destroy(ctx: *mut rt_ctx);
+    pub fn rt_last_error(ctx: *const rt_ctx) -> *const c_char;
+    pub fn rt_upload_scene(ctx: *mut rt_ctx, scene: *const rt_scene) -> c_int;
+    pub fn rt_render(
+        ctx: *mut rt_ctx,
+        cam: *const rt_camera,
+        params: *const rt_params,
+        out_rgb: *mut f32, // width*height*3, row-major, y = 0 is the top row, linear radiance means
+        stats: *mut rt_stats,
+    ) -> c_int;
+}
