@@ -15,13 +15,15 @@
 //!   screen.rs:56    struct Camera { ..., pub shutter: Option<(f64, f64)> } // `Uniform<f64>` (screen.rs:65) hides its
 //!                   bounds; CameraBuilder::build (screen.rs:112-147) stores the (open, close) pair it was given
 //!
+//! In each existing `impl Hittable / Material / Texture for X` block the new method forwards to the inherent
+//! `X::flatten_impl` defined below:  fn flatten(&self, out: &mut FlatScene) -> ... { self.flatten_impl(out) }
+//!
 //! ---- three one-line additions inside the adapters (material.rs) -----------------------------------------------
 //!   fBm        (:184)  *self.desc() = NoiseDesc { op: RT_NOISE_FBM,        lacunarity, gain, layers, ..*self.desc() };
 //!   turbulence (:211)  *self.desc() = NoiseDesc { op: RT_NOISE_TURBULENCE, lacunarity, gain, layers, ..*self.desc() };
 //!   marbled    (:241)  let d = self.desc(); d.marbled = true; d.sin_freq = sin_freq; d.phase = phase_shift;
 //!                      d.marble_gain = gain;   // `gain` = self.freq() * noise_gain, material.rs:251
 use std::ffi::CStr;
-use std::sync::Arc;
 
 use anyhow::{anyhow, Result};
 
@@ -167,9 +169,8 @@ impl Checkered<Color, Color> {
     }
 }
 // any other Checkered<O, E>: Err(FlattenError::Unsupported("Checkered of textures"))
-impl<T: Texture + Send + std::fmt::Debug> /* Texture for */ Arc<T> {
-    // material.rs:128-133 forwards `value`; `flatten` forwards the same way: (**self).flatten(out)
-}
+// `impl Texture for Arc<T>` (material.rs:128-133) forwards `value`; it forwards `flatten` the same way:
+//     fn flatten(&self, out: &mut FlatScene) -> Result<i32, FlattenError> { <T as Texture>::flatten(self, out) }
 
 fn noise_texture(kind: i32, freq: f64, d: &NoiseDesc, table_id: i32) -> rt_texture {
     rt_texture {
