@@ -8,7 +8,7 @@ w = api.World("FinalStatic", seed=1, aspect=1.5)
 ctx.upload(w.scene)
 acc = torch.zeros(800, 1200, 3, dtype=torch.float32, device="cuda")
 for spp in [125, 250, 500, 1000, 2000]:
-    p = api.make_params(1200, 800, spp, seed=w.render_seed)
+    p = api.make_params(1200, 800, spp, seed=w.render_seed, max_depth=int(os.environ.get("MAXD", "100")))
     st = ctx.render_accum_device(w.camera, p, acc.data_ptr())
     st = ctx.render_accum_device(w.camera, p, acc.data_ptr())
     print("spp", spp, "kernel_ms %.2f" % st.kernel_ms, "ms per 1000 spp %.2f" % (st.kernel_ms * 1000 / spp), flush=True)
