@@ -164,7 +164,8 @@ def main():
                 "peak": FP32_VALU_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / FP32_VALU_PEAK_TFLOPS,
-                "traffic": traffic,
+                "traffic": traffic,  # HBM bytes per launch from the committed PMC passes (profiles/hbm_traffic.json)
+                "traffic_frac_of_hbm_peak": (traffic / (kernel_ms / max(launches, 1) * 1e-3) / 8e12) if traffic else None,
                 "flops_per_ray": flops_per_ray,
                 "kernel_ms_per_launch": kernel_ms / max(launches, 1),
                 "launches_per_step": launches / args.steps,
