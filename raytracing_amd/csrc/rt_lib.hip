@@ -28,6 +28,7 @@ constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
 // Work units are 8x8 pixels x kUnitSppA samples (3072 items, ~65 scan passes), except for the last kTailSpan (or
 // 1/8 of the) samples of a launch, which are cut into kUnitSppB-sample units so that the waves finish together.
 constexpr uint32_t kUnitSppA = 48, kUnitSppB = 8, kTailSpan = 128;
+constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes are computed in 32 bits)
 constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
 constexpr float kBigCenter = 500.0f;
 
@@ -660,6 +661,8 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     if (rc != RT_OK) return rc;
     if (!cam || !p || !d_out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     if (p->width < 2 || p->height < 2) return fail(c, RT_ERR_BAD_ARG, "width and height must be >= 2 (i = x/(W-1), main.rs:81)");
+    if (p->width > 65536 || p->height > 65536 || (uint64_t)p->width * p->height > (1ull << 28))
+        return fail(c, RT_ERR_BAD_ARG, "image larger than 65536 on a side or 2^28 pixels");
     if (p->spp == 0 || p->max_depth == 0) return fail(c, RT_ERR_BAD_ARG, "spp and max_depth are NonZero in the reference (config.rs:52,56)");
     if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(c, RT_ERR_BAD_ARG, "image too large");
     if ((uint64_t)p->spp_offset + p->spp > 0xFFFFFFFFull) return fail(c, RT_ERR_BAD_ARG, "spp_offset + spp overflows 32 bits");
@@ -783,6 +786,7 @@ int rt_intersect_batch(rt_ctx* c, const rt_ray* rays, uint32_t n, float t_min, r
     int rc = check_ready(c);
     if (rc != RT_OK) return rc;
     if (n == 0) return RT_OK;
+    if (n > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "batch larger than 2^30 elements");
     if (!rays || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     TmpBuf dr, dh;
     RT_TMP(c, dr, n * sizeof(rt_ray));
@@ -800,6 +804,7 @@ int rt_scatter_batch(rt_ctx* c, const rt_ray* rays, const rt_hit* hits, const fl
     int rc = check_ready(c);
     if (rc != RT_OK) return rc;
     if (n == 0) return RT_OK;
+    if (n > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "batch larger than 2^30 elements");
     if (!rays || !hits || !u4 || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     for (uint32_t i = 0; i < n; ++i)
         if (hits[i].hit && (hits[i].sphere_id < 0 || hits[i].sphere_id >= c->S.n_spheres))
@@ -824,6 +829,7 @@ int rt_texture_batch(rt_ctx* c, int32_t tex_id, const float* p3, uint32_t n, flo
     int rc = check_ready(c);
     if (rc != RT_OK) return rc;
     if (n == 0) return RT_OK;
+    if (n > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "batch larger than 2^30 elements");
     if (!p3 || !out3) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     TmpBuf dp, dout;
     RT_TMP(c, dp, n * 3 * sizeof(float));
@@ -842,6 +848,7 @@ int rt_camera_rays(rt_ctx* c, const rt_camera* cam, const float* ij2, const floa
     if (!c) return RT_ERR_BAD_ARG;
     RT_HIP(c, hipSetDevice(c->device));
     if (n == 0) return RT_OK;
+    if (n > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "batch larger than 2^30 elements");
     if (!cam || !ij2 || !u4 || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     TmpBuf dij, du, dout;
     RT_TMP(c, dij, n * 2 * sizeof(float));
@@ -861,6 +868,7 @@ int rt_rng_batch(rt_ctx* c, uint64_t seed, const uint32_t* c4, uint32_t n, uint3
     if (!c) return RT_ERR_BAD_ARG;
     RT_HIP(c, hipSetDevice(c->device));
     if (n == 0) return RT_OK;
+    if (n > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "batch larger than 2^30 elements");
     if (!c4 || !out4) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     TmpBuf dc, dout;
     RT_TMP(c, dc, n * 4 * sizeof(uint32_t));
@@ -879,6 +887,7 @@ int rt_encode(rt_ctx* c, const float* rgb, uint32_t n_pixels, uint32_t* out_0rgb
     RT_HIP(c, hipSetDevice(c->device));
     if (n_invalid) *n_invalid = 0;
     if (n_pixels == 0) return RT_OK;
+    if (n_pixels > kMaxBatch) return fail(c, RT_ERR_BAD_ARG, "more than 2^30 pixels");
     if (!rgb || !out_0rgb) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     TmpBuf din, dout, dcnt;
     RT_TMP(c, din, (size_t)n_pixels * 3 * sizeof(float));

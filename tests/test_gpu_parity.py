@@ -232,7 +232,7 @@ def test_render_properties_full_size(ctx, api):
         assert img.shape == (H, W, 3) and np.isfinite(img).all() and st.samples == W * H * 4
         assert img.sum() > 0
     # argument errors
-    for bad in (dict(width=1), dict(spp=0), dict(max_depth=0)):
+    for bad in (dict(width=1), dict(spp=0), dict(max_depth=0), dict(width=70000), dict(width=20000, height=20000)):
         kw = dict(width=16, height=16, spp=1, max_depth=5)
         kw.update(bad)
         with pytest.raises(api.RtError) as e:
