@@ -29,7 +29,8 @@ extern "C" {
 
 /* Limits.  The sphere lists are streamed through the scalar cache (not LDS), so the sphere limit is a sanity bound
  * on a brute-force scan (cost per ray segment is linear in it), not a capacity: every reference scene has < 500.
- * Noise tables (2 KiB each) are staged in LDS. */
+ * Noise tables (2 KiB each) are staged in LDS.  Images: 2 <= width, height <= 65536 and at most 2^28 pixels; batch entry
+ * points take at most 2^30 elements per call. */
 #define RT_MAX_SPHERES 16384
 #define RT_MAX_MATERIALS 16384
 #define RT_MAX_TEXTURES 16384
