@@ -148,8 +148,7 @@ typedef struct rt_params {
                             multi-GPU spp partitioning / progressive rendering */
     uint64_t seed;       /* counter-RNG key (replaces main.rs:60,71) */
     float t_min;         /* 0.001 in the reference (main.rs:116) */
-    uint32_t reserved;   /* 0.  Test hook: n > 0 forces work units of n samples per pixel (the image does not depend
-                            on it: tests/test_gpu_parity.py::test_work_unit_size_does_not_change_the_image) */
+    uint32_t reserved;   /* must be 0 (RT_ERR_BAD_ARG otherwise) */
 } rt_params;
 
 typedef struct rt_stats {

@@ -1,0 +1,25 @@
+/* rtx_hip_debug.h — test and tuning hooks of librtx_hip.so.  NOT part of the drop-in ABI (include/rtx_hip.h):
+ * nothing here has a counterpart in the reference, a caller of the path never needs it, and the rendered image
+ * does not depend on any of it (tests/test_gpu_parity.py::test_work_unit_size_does_not_change_the_image).
+ * The library reads no environment variables. */
+#ifndef RTX_HIP_DEBUG_H
+#define RTX_HIP_DEBUG_H
+
+#include "rtx_hip.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Force the work-unit schedule of the render kernel: units of `unit_a` samples per pixel, except for the last
+ * `tail_span` samples of a launch, which are cut into `unit_b`-sample units.  0 / 0 / -1 restore the defaults. */
+int rt_debug_set_work_units(rt_ctx* ctx, uint32_t unit_a, uint32_t unit_b, int32_t tail_span);
+
+/* world_order != 0: the next rt_upload_scene keeps the scan lists in the caller's order instead of sorting them
+ * along a Morton curve (A/B switch for the lazy root extraction; results are identical). */
+int rt_debug_set_scan_order(rt_ctx* ctx, int world_order);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTX_HIP_DEBUG_H */

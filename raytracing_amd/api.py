@@ -104,6 +104,8 @@ ABI_SYMBOLS = [
     "rt_render_accum_device", "rt_intersect_batch", "rt_scatter_batch", "rt_texture_batch", "rt_camera_rays",
     "rt_rng_batch", "rt_encode", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
+    # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
+    "rt_debug_set_work_units", "rt_debug_set_scan_order",
 ]
 
 _lib = None
@@ -141,6 +143,8 @@ def load() -> C.CDLL:
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Scene)]
     lib.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
     lib.rt_render_accum_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
+    lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
+    lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
     lib.rt_intersect_batch.argtypes = [vp, vp, C.c_uint32, C.c_float, vp]
     lib.rt_scatter_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, vp]
     lib.rt_texture_batch.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp]
@@ -318,6 +322,13 @@ class Context:
         self._check(self.lib.rt_render_accum_device(self._h, C.byref(cam), C.byref(params),
                                                     C.c_void_p(device_ptr), C.byref(st)))
         return st
+
+    def debug_set_work_units(self, unit_a: int = 0, unit_b: int = 0, tail_span: int = -1):
+        """include/rtx_hip_debug.h: force the work-unit schedule (0, 0, -1 = defaults)."""
+        self._check(self.lib.rt_debug_set_work_units(self._h, unit_a, unit_b, tail_span))
+
+    def debug_set_scan_order(self, world_order: bool):
+        self._check(self.lib.rt_debug_set_scan_order(self._h, 1 if world_order else 0))
 
     def intersect_batch(self, rays: np.ndarray, t_min: float = 1e-3) -> np.ndarray:
         rays = np.ascontiguousarray(rays, dtype=ray_dtype)

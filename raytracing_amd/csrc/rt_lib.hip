@@ -386,6 +386,13 @@ struct rt_ctx {
     size_t out_cap = 0;
     int cu_count = 256;
     bool has_noise = false;  // the uploaded scene references a value/Perlin noise texture
+    int blocks_per_cu = 0;   // resident workgroups of the scene's render-kernel variant (computed at upload)
+    // a pinned word for the ray count
+    unsigned long long* pinned_rays = nullptr;
+    // rt_debug_* (include/rtx_hip_debug.h): work-unit sizes forced by a test, scan lists kept in world order
+    uint32_t dbg_unit_a = 0, dbg_unit_b = 0;
+    int32_t dbg_tail_span = -1;
+    bool dbg_world_order = false;
 };
 
 namespace {
@@ -458,6 +465,7 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev2);
     if (e == hipSuccess) e = hipEventCreate(&c->ev3);
     if (e == hipSuccess) e = hipMalloc((void**)&c->rays, 2 * sizeof(unsigned long long));  // [0] ray counter, [1] unit counter
+    if (e == hipSuccess) e = hipHostMalloc((void**)&c->pinned_rays, 2 * sizeof(unsigned long long), hipHostMallocDefault);
     if (e != hipSuccess) {
         g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
         rt_destroy(c);
@@ -483,6 +491,7 @@ void rt_destroy(rt_ctx* c) {
     if (c->accum) (void)hipFree(c->accum);
     if (c->rays) (void)hipFree(c->rays);
     if (c->out) (void)hipFree(c->out);
+    if (c->pinned_rays) (void)hipHostFree(c->pinned_rays);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->ev2) (void)hipEventDestroy(c->ev2);
@@ -558,9 +567,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     }
     // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
     // group are then neighbours, so the groups met by a wave's rays are few (rt_device.h, scan_spheres).  Ties in
-    // the curve keep world order (stable sort); RTX_SCAN_ORDER=world keeps the caller's order (A/B switch).
-    const char* order_env = std::getenv("RTX_SCAN_ORDER");
-    if (!(order_env && std::strcmp(order_env, "world") == 0)) {
+    // the curve keep world order (stable sort); rt_debug_set_scan_order keeps the caller's order (A/B switch).
+    if (!c->dbg_world_order) {
         auto morton_order = [](const std::vector<float4>& ctr) {
             std::vector<uint32_t> perm(ctr.size());
             std::iota(perm.begin(), perm.end(), 0u);
@@ -651,34 +659,40 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     c->lds_scene = align16(lds_need);
     c->has_noise = false;
     for (uint32_t i = 0; i < s->n_textures; ++i) c->has_noise |= s->textures[i].kind >= RT_TEX_VALUE_NOISE;
+    // resident workgroups per CU of the variant this scene runs (the persistent grid is exactly that many)
+    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
+    c->blocks_per_cu = 0;
+    RT_HIP(c, c->has_noise ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->blocks_per_cu, render_kernel<true>, kBlock, lds_bytes)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->blocks_per_cu, render_kernel<false>, kBlock, lds_bytes));
     c->has_scene = true;
     return RT_OK;
 }
 
-static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* d_out, bool mean,
-                         rt_stats* stats) {
+// Argument checks shared by the render entry points; nothing is allocated or touched before they pass.
+static int check_render_args(rt_ctx* c, const rt_camera* cam, const rt_params* p, const void* out) {
     int rc = check_ready(c);
     if (rc != RT_OK) return rc;
-    if (!cam || !p || !d_out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
+    if (!cam || !p || !out) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
     if (p->width < 2 || p->height < 2) return fail(c, RT_ERR_BAD_ARG, "width and height must be >= 2 (i = x/(W-1), main.rs:81)");
     if (p->width > 65536 || p->height > 65536 || (uint64_t)p->width * p->height > (1ull << 28))
         return fail(c, RT_ERR_BAD_ARG, "image larger than 65536 on a side or 2^28 pixels");
     if (p->spp == 0 || p->max_depth == 0) return fail(c, RT_ERR_BAD_ARG, "spp and max_depth are NonZero in the reference (config.rs:52,56)");
-    if ((uint64_t)p->width * p->height > (1ull << 31)) return fail(c, RT_ERR_BAD_ARG, "image too large");
     if ((uint64_t)p->spp_offset + p->spp > 0xFFFFFFFFull) return fail(c, RT_ERR_BAD_ARG, "spp_offset + spp overflows 32 bits");
     if (!(p->t_min >= 0.0f)) return fail(c, RT_ERR_BAD_ARG, "t_min must be >= 0");
+    if (p->reserved != 0) return fail(c, RT_ERR_BAD_ARG, "rt_params.reserved must be 0");
+    return RT_OK;
+}
 
+// The render proper: clears the workspace, launches the path-trace kernel(s) and the finalize on the ctx stream.
+// `accum` (W*H*3 u64) and `counters` ([0] rays, [1] unit queue) are the workspace: the ctx's own allocation or
+// this device's static scratch array.  Allocates nothing.  sync = false leaves the work in flight (multi-device
+// callers launch on every device first); render_finish waits and fills the stats.
+static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, unsigned long long* accum,
+                         unsigned long long* counters, float* d_out, double out_scale, uint32_t* n_launches) {
     const size_t n_px = (size_t)p->width * p->height, n_el = n_px * 3;
-    if (c->accum_cap < n_el) {
-        if (c->accum) (void)hipFree(c->accum);
-        c->accum = nullptr; c->accum_cap = 0;
-        if (hipMalloc((void**)&c->accum, n_el * sizeof(unsigned long long)) != hipSuccess)
-            return fail(c, RT_ERR_ALLOC, "cannot allocate the radiance accumulators");
-        c->accum_cap = n_el;
-    }
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
-    RT_HIP(c, hipMemsetAsync(c->accum, 0, n_el * sizeof(unsigned long long), c->stream));
-    RT_HIP(c, hipMemsetAsync(c->rays, 0, sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(accum, 0, n_el * sizeof(unsigned long long), c->stream));
+    RT_HIP(c, hipMemsetAsync(counters, 0, sizeof(unsigned long long), c->stream));
 
     RenderArgs A{};
     A.S = c->S;
@@ -691,8 +705,8 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
     A.t_min = p->t_min;
     A.lds_scene_bytes = (uint32_t)c->lds_scene;
-    A.accum = c->accum;
-    A.rays = c->rays;
+    A.accum = accum;
+    A.rays = counters;
     const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
 
     // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * n_levels work units that a grid of
@@ -700,12 +714,9 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     // samples so no single kernel runs for minutes.
     const uint64_t max_samples_per_launch = 1ull << 31;
     uint32_t spp_per_launch = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(p->spp, max_samples_per_launch / n_px));
-    int blocks_per_cu = 0;
     const bool noise = c->has_noise;  // noise-free scenes run the variant with the noise textures compiled out
-    RT_HIP(c, noise ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<true>, kBlock, lds_bytes)
-                    : hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, render_kernel<false>, kBlock, lds_bytes));
-    if (blocks_per_cu < 1) return fail(c, RT_ERR_HIP, "render kernel does not fit a compute unit");
-    const uint32_t resident_blocks = (uint32_t)c->cu_count * (uint32_t)blocks_per_cu;
+    if (c->blocks_per_cu < 1) return fail(c, RT_ERR_HIP, "render kernel does not fit a compute unit");
+    const uint32_t resident_blocks = (uint32_t)c->cu_count * (uint32_t)c->blocks_per_cu;
     uint32_t done = 0, launches = 0;
     RT_HIP(c, hipEventRecord(c->ev1, c->stream));
     while (done < p->spp) {
@@ -718,10 +729,9 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         // 48-spp units with a 128-spp tail of 8-spp units 261.8 ms, 40/8/96 260.6 ms, 64/8/64 269 ms; a schedule of
         // halving sizes cut the accumulator traffic 6x but cost 4-6 %.
         uint32_t ua = kUnitSppA, ub = kUnitSppB, span = std::max(kTailSpan, spp_l / 8);
-        if (const char* e = std::getenv("RTX_UNIT_A")) ua = std::max(1, std::atoi(e));        // tuning knobs
-        if (const char* e = std::getenv("RTX_UNIT_B")) ub = std::max(1, std::atoi(e));
-        if (const char* e = std::getenv("RTX_TAIL_SPAN")) span = (uint32_t)std::max(0, std::atoi(e));
-        if (p->reserved) { ua = ub = p->reserved; span = 0; }  // debug/test hook: force spp per unit
+        if (c->dbg_unit_a) ua = c->dbg_unit_a;  // rt_debug_set_work_units (tests, sweeps): the image does not depend on these
+        if (c->dbg_unit_b) ub = c->dbg_unit_b;
+        if (c->dbg_tail_span >= 0) span = (uint32_t)c->dbg_tail_span;
         span = std::min(span, spp_l);
         A.spp_a = ua; A.spp_b = ub;
         A.n_a = (spp_l - span) / ua;
@@ -730,8 +740,8 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         const uint64_t n_units = (uint64_t)A.n_tiles * chunks;
         if (n_units > 0xFFFFFFF0ull) return fail(c, RT_ERR_BAD_ARG, "too many work units in one launch");
         A.n_units = (uint32_t)n_units;
-        A.unit_counter = reinterpret_cast<unsigned int*>(c->rays + 1);
-        RT_HIP(c, hipMemsetAsync(c->rays + 1, 0, sizeof(unsigned long long), c->stream));
+        A.unit_counter = reinterpret_cast<unsigned int*>(counters + 1);
+        RT_HIP(c, hipMemsetAsync(counters + 1, 0, sizeof(unsigned long long), c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
         if (noise) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
@@ -740,17 +750,21 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
         ++launches;
     }
     RT_HIP(c, hipEventRecord(c->ev2, c->stream));
-    const double scale = (1.0 / 4294967296.0) / (mean ? (double)p->spp : 1.0);
-    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream, c->accum, d_out, n_el, scale);
+    hipLaunchKernelGGL(finalize_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, c->stream, accum, d_out, n_el, out_scale);
     RT_HIP(c, hipGetLastError());
+    RT_HIP(c, hipMemcpyAsync(c->pinned_rays, counters, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
     RT_HIP(c, hipEventRecord(c->ev3, c->stream));
+    *n_launches = launches;
+    return RT_OK;
+}
+
+static int render_finish(rt_ctx* c, const rt_params* p, uint32_t launches, rt_stats* stats) {
+    RT_HIP(c, hipSetDevice(c->device));
     RT_HIP(c, hipStreamSynchronize(c->stream));
     if (stats) {
         std::memset(stats, 0, sizeof(*stats));
-        unsigned long long nr = 0;
-        RT_HIP(c, hipMemcpy(&nr, c->rays, sizeof(nr), hipMemcpyDeviceToHost));
-        stats->rays_traced = nr;
-        stats->samples = (uint64_t)n_px * p->spp;
+        stats->rays_traced = c->pinned_rays[0];
+        stats->samples = (uint64_t)p->width * p->height * p->spp;
         RT_HIP(c, hipEventElapsedTime(&stats->kernel_ms, c->ev1, c->ev2));
         RT_HIP(c, hipEventElapsedTime(&stats->total_ms, c->ev0, c->ev3));
         stats->n_launches = launches;
@@ -758,24 +772,56 @@ static int render_common(rt_ctx* c, const rt_camera* cam, const rt_params* p, fl
     return RT_OK;
 }
 
+// ctx-owned accumulators, grown on demand (the allocating entry points)
+static int ensure_accum(rt_ctx* c, size_t n_el) {
+    if (c->accum_cap >= n_el) return RT_OK;
+    if (c->accum) (void)hipFree(c->accum);
+    c->accum = nullptr; c->accum_cap = 0;
+    if (hipMalloc((void**)&c->accum, n_el * sizeof(unsigned long long)) != hipSuccess)
+        return fail(c, RT_ERR_ALLOC, "cannot allocate the radiance accumulators");
+    c->accum_cap = n_el;
+    return RT_OK;
+}
+
+static const double kFixedToFloat = 1.0 / 4294967296.0;
+
 int rt_render_accum_device(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* d_sum_rgb, rt_stats* stats) {
-    return render_common(c, cam, p, d_sum_rgb, false, stats);
+    int rc = check_render_args(c, cam, p, d_sum_rgb);
+    if (rc != RT_OK) return rc;
+    if ((rc = ensure_accum(c, (size_t)p->width * p->height * 3)) != RT_OK) return rc;
+    uint32_t launches = 0;
+    if ((rc = render_launch(c, cam, p, c->accum, c->rays, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK) return rc;
+    return render_finish(c, p, launches, stats);
 }
 
 int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rgb, rt_stats* stats) {
-    if (!c || !p || !out_rgb) return fail(c, RT_ERR_BAD_ARG, "NULL argument");
-    RT_HIP(c, hipSetDevice(c->device));
+    int rc = check_render_args(c, cam, p, out_rgb);  // before any allocation: a rejected call leaves the ctx as it was
+    if (rc != RT_OK) return rc;
     const size_t n_el = (size_t)p->width * p->height * 3;
+    if ((rc = ensure_accum(c, n_el)) != RT_OK) return rc;
     if (c->out_cap < n_el) {
         if (c->out) (void)hipFree(c->out);
         c->out = nullptr; c->out_cap = 0;
-        if (hipMalloc((void**)&c->out, std::max<size_t>(n_el, 1) * sizeof(float)) != hipSuccess)
+        if (hipMalloc((void**)&c->out, n_el * sizeof(float)) != hipSuccess)
             return fail(c, RT_ERR_ALLOC, "cannot allocate the output image");
         c->out_cap = n_el;
     }
-    int rc = render_common(c, cam, p, c->out, true, stats);
-    if (rc != RT_OK) return rc;
+    uint32_t launches = 0;
+    if ((rc = render_launch(c, cam, p, c->accum, c->rays, c->out, kFixedToFloat / (double)p->spp, &launches)) != RT_OK) return rc;
+    if ((rc = render_finish(c, p, launches, stats)) != RT_OK) return rc;
     RT_HIP(c, hipMemcpy(out_rgb, c->out, n_el * sizeof(float), hipMemcpyDeviceToHost));
+    return RT_OK;
+}
+
+// ---- debug hooks (include/rtx_hip_debug.h): not part of the drop-in ABI ----------------------------
+int rt_debug_set_work_units(rt_ctx* c, uint32_t unit_a, uint32_t unit_b, int32_t tail_span) {
+    if (!c) return RT_ERR_BAD_ARG;
+    c->dbg_unit_a = unit_a; c->dbg_unit_b = unit_b; c->dbg_tail_span = tail_span;
+    return RT_OK;
+}
+int rt_debug_set_scan_order(rt_ctx* c, int world_order) {
+    if (!c) return RT_ERR_BAD_ARG;
+    c->dbg_world_order = world_order != 0;
     return RT_OK;
 }
 

@@ -244,14 +244,17 @@ def test_work_unit_size_does_not_change_the_image(ctx, api):
     """The persistent waves pull (tile, spp-chunk) units from a counter and switch units without draining (paths
     of the old unit finish as orphans that add straight into the global sums). Whatever the unit size, which wave
     ran a unit, or how many switches happened, the fixed-point sums - hence the image and the ray count - are
-    identical bit for bit. rt_params.reserved is the debug hook that forces the samples per unit."""
+    identical bit for bit. rt_debug_set_work_units (include/rtx_hip_debug.h) forces the samples per unit."""
     w = api.World("Random", seed=3, aspect=328 / 200)  # moving spheres + checker, ragged width (328 = 41 tiles)
     ctx.upload(w.scene)
     base = None
     for unit in (0, 1, 7, 40, 1000):
         p = api.make_params(328, 200, 40, seed=w.render_seed)
-        p.reserved = unit
-        img, st = ctx.render(w.camera, p)
+        ctx.debug_set_work_units(unit, unit, 0 if unit else -1)
+        try:
+            img, st = ctx.render(w.camera, p)
+        finally:
+            ctx.debug_set_work_units()
         if base is None:
             base = (img, st.rays_traced)
             assert np.isfinite(img).all() and st.samples == 328 * 200 * 40

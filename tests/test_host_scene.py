@@ -183,7 +183,8 @@ def test_birds_eye_view_up(api):  # view_up_degrees(15, Axis::Y), screen.rs:233-
 
 # ---- the C ABI -----------------------------------------------------------------------------------------------
 def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "rtx_hip.h")).read()
+    src = "".join(open(os.path.join(ROOT, "include", h)).read() for h in sorted(os.listdir(os.path.join(ROOT, "include")))
+                  if h.endswith(".h"))  # every header under include/
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     return sorted(set(re.findall(r"\b(rth?_[a-z0-9_]+)\s*\(", src)))
 

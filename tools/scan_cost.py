@@ -12,7 +12,7 @@ for k in (1, 9, 33, 65, 129, 257, 385, full):
     s.n_spheres = k
     ctx.upload(s)
     p = api.make_params(1200, 800, 64, seed=3)
-    p.reserved = 64  # one chunk: 4096 items per wave, so the per-wave tail does not pollute the fit
+    ctx.debug_set_work_units(64, 64, 0)  # one chunk: 4096 items per wave, so the per-wave tail does not pollute the fit
     ctx.render(w.camera, p)
     _, st = ctx.render(w.camera, p)
     clk = 2.39e9
