@@ -35,6 +35,9 @@ extern "C" {
 #define RT_MAX_MATERIALS 16384
 #define RT_MAX_TEXTURES 16384
 #define RT_MAX_NOISE_TABLES 4
+/* Largest image (pixels) of rt_render_accum_device_noalloc: its workspace is a static device array of
+ * RT_NOALLOC_MAX_PIXELS * 24 bytes (24 MiB) per GPU.  1200x800 (BASELINE configs[1]-[3]) fits; 3840x2160 does not. */
+#define RT_NOALLOC_MAX_PIXELS (1u << 20)
 
 typedef enum rt_status {
     RT_OK = 0,
@@ -213,6 +216,17 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_params* params,
  * the fp32 accumulator that multi-GPU callers sum with an RCCL reduce. */
 int rt_render_accum_device(rt_ctx* ctx, const rt_camera* cam, const rt_params* params,
                            float* d_sum_rgb, rt_stats* stats);
+
+/* rt_render_accum_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops,
+ * harnesses that forbid hipMalloc).  No counterpart in the reference (it has no device, main.rs:64-92 allocates
+ * nothing either).  Same arguments, same kernels and bit-identical output, but the fixed-point radiance
+ * accumulators and the launch counters live in a static device array inside the library instead of a buffer the
+ * ctx hipMallocs on demand, so this entry point calls no hipMalloc / hipFree or other allocating routine.
+ * Limit: width*height <= RT_NOALLOC_MAX_PIXELS, larger images return RT_ERR_BAD_ARG.  The array is per GPU, not
+ * per ctx, and keeps the previous call's contents (each call clears what it uses): two such calls that overlap
+ * on one GPU (two ctxs, two threads) race; calls on different GPUs do not. */
+int rt_render_accum_device_noalloc(rt_ctx* ctx, const rt_camera* cam, const rt_params* params,
+                                   float* d_sum_rgb, rt_stats* stats);
 
 /* ---- fixed-batch entry points (parity tests; host buffers) -------------------- */
 /* `HitList::hit(ray, t_min..inf)` (hit.rs:100-110) for n rays. */

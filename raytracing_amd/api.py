@@ -101,7 +101,7 @@ assert ray_dtype.itemsize == 28 and hit_dtype.itemsize == 44 and scatter_dtype.i
 # every symbol include/rtx_hip.h declares (tests check the library exports them all)
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_abi_version", "rt_upload_scene", "rt_render",
-    "rt_render_accum_device", "rt_intersect_batch", "rt_scatter_batch", "rt_texture_batch", "rt_camera_rays",
+    "rt_render_accum_device", "rt_render_accum_device_noalloc", "rt_intersect_batch", "rt_scatter_batch", "rt_texture_batch", "rt_camera_rays",
     "rt_rng_batch", "rt_encode", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
@@ -143,6 +143,7 @@ def load() -> C.CDLL:
     lib.rt_upload_scene.argtypes = [vp, C.POINTER(Scene)]
     lib.rt_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
     lib.rt_render_accum_device.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
+    lib.rt_render_accum_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
     lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
     lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
     lib.rt_intersect_batch.argtypes = [vp, vp, C.c_uint32, C.c_float, vp]
@@ -321,6 +322,13 @@ class Context:
         st = Stats()
         self._check(self.lib.rt_render_accum_device(self._h, C.byref(cam), C.byref(params),
                                                     C.c_void_p(device_ptr), C.byref(st)))
+        return st
+
+    def render_accum_device_noalloc(self, cam: Camera, params: Params, device_ptr: int) -> Stats:
+        """rt_render_accum_device_noalloc: the same, with the workspace in the library's static device array."""
+        st = Stats()
+        self._check(self.lib.rt_render_accum_device_noalloc(self._h, C.byref(cam), C.byref(params),
+                                                            C.c_void_p(device_ptr), C.byref(st)))
         return st
 
     def debug_set_work_units(self, unit_a: int = 0, unit_b: int = 0, tail_span: int = -1):

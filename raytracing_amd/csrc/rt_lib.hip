@@ -32,6 +32,14 @@ constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes
 constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
 constexpr float kBigCenter = 500.0f;
 
+// Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
+// radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
+// per GPU, held until the process ends (24 MiB + 256 B).  In host code this NAME is only a handle for
+// hipGetSymbolAddress (rt_create); everything else uses the per-device address kept in rt_ctx::scratch.
+constexpr size_t kScratchAccum = (size_t)RT_NOALLOC_MAX_PIXELS * 3;  // u64 elements
+constexpr size_t kScratchWords = kScratchAccum + 32;                 // + [0] ray counter, [1] unit counter (+ pad)
+static __device__ __align__(256) unsigned long long g_noalloc_scratch[kScratchWords];
+
 struct RenderArgs {
     DevScene S;
     rt_camera cam;
@@ -387,7 +395,8 @@ struct rt_ctx {
     int cu_count = 256;
     bool has_noise = false;  // the uploaded scene references a value/Perlin noise texture
     int blocks_per_cu = 0;   // resident workgroups of the scene's render-kernel variant (computed at upload)
-    // a pinned word for the ray count
+    // this device's copy of g_noalloc_scratch (hipGetSymbolAddress at rt_create) and a pinned word for the ray count
+    unsigned long long* scratch = nullptr;
     unsigned long long* pinned_rays = nullptr;
     // rt_debug_* (include/rtx_hip_debug.h): work-unit sizes forced by a test, scan lists kept in world order
     uint32_t dbg_unit_a = 0, dbg_unit_b = 0;
@@ -466,6 +475,9 @@ int rt_create(int device_ordinal, rt_ctx** out) {
     if (e == hipSuccess) e = hipEventCreate(&c->ev3);
     if (e == hipSuccess) e = hipMalloc((void**)&c->rays, 2 * sizeof(unsigned long long));  // [0] ray counter, [1] unit counter
     if (e == hipSuccess) e = hipHostMalloc((void**)&c->pinned_rays, 2 * sizeof(unsigned long long), hipHostMallocDefault);
+    // this device's address of the no-alloc workspace (each GPU holds its own copy of the array)
+    if (e == hipSuccess) e = hipGetSymbolAddress((void**)&c->scratch, HIP_SYMBOL(g_noalloc_scratch));
+    if (e == hipSuccess && !c->scratch) e = hipErrorInvalidSymbol;
     if (e != hipSuccess) {
         g_create_error = std::string("rt_create: ") + hipGetErrorString(e);
         rt_destroy(c);
@@ -791,6 +803,22 @@ int rt_render_accum_device(rt_ctx* c, const rt_camera* cam, const rt_params* p, 
     if ((rc = ensure_accum(c, (size_t)p->width * p->height * 3)) != RT_OK) return rc;
     uint32_t launches = 0;
     if ((rc = render_launch(c, cam, p, c->accum, c->rays, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK) return rc;
+    return render_finish(c, p, launches, stats);
+}
+
+// Same render with NO allocation: the accumulators and counters live in this device's static scratch array.
+int rt_render_accum_device_noalloc(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* d_sum_rgb,
+                                   rt_stats* stats) {
+    int rc = check_render_args(c, cam, p, d_sum_rgb);
+    if (rc != RT_OK) return rc;
+    if ((uint64_t)p->width * p->height > RT_NOALLOC_MAX_PIXELS)
+        return fail(c, RT_ERR_BAD_ARG, "rt_render_accum_device_noalloc: image larger than RT_NOALLOC_MAX_PIXELS pixels "
+                                       "(the static workspace is fixed; use rt_render_accum_device)");
+    uint32_t launches = 0;
+    // every call on this GPU shares the array and it keeps the last call's contents: render_launch clears the
+    // W*H*3 accumulators it uses and both counters before the kernel reads them
+    if ((rc = render_launch(c, cam, p, c->scratch, c->scratch + kScratchAccum, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK)
+        return rc;
     return render_finish(c, p, launches, stats);
 }
 
