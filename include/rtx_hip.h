@@ -35,6 +35,7 @@ extern "C" {
 #define RT_MAX_MATERIALS 16384
 #define RT_MAX_TEXTURES 16384
 #define RT_MAX_NOISE_TABLES 4
+#define RT_MAX_DEVICES 16 /* devices of one rt_multi (one node) */
 /* Largest image (pixels) of rt_render_accum_device_noalloc: its workspace is a static device array of
  * RT_NOALLOC_MAX_PIXELS * 24 bytes (24 MiB) per GPU.  1200x800 (BASELINE configs[1]-[3]) fits; 3840x2160 does not. */
 #define RT_NOALLOC_MAX_PIXELS (1u << 20)
@@ -46,7 +47,8 @@ typedef enum rt_status {
     RT_ERR_SCENE_TOO_LARGE = -3,
     RT_ERR_NO_SCENE = -4,
     RT_ERR_NO_DEVICE = -5,
-    RT_ERR_ALLOC = -6
+    RT_ERR_ALLOC = -6,
+    RT_ERR_RCCL = -7 /* librccl missing, or an RCCL call failed (multi-device entry points only) */
 } rt_status;
 
 /* `impl Material for ...` in reference src/material.rs:35-112 */
@@ -246,6 +248,38 @@ int rt_camera_rays(rt_ctx* ctx, const rt_camera* cam, const float* ij2,
 /* The counter RNG itself: Philox4x32-10, key = seed, counter = (c0,c1,c2,c3). */
 int rt_rng_batch(rt_ctx* ctx, uint64_t seed, const uint32_t* counters4, uint32_t n,
                  uint32_t* out4);
+
+/* ---- multi-device (one process, the GPUs of one node) ------------------------------------------------------
+ * The reference's only parallelism is rayon over rows (main.rs:64-67); on N GPUs the samples-per-pixel are split:
+ * device g renders sample indices [first_g, first_g + count_g) of every pixel (rt_partition_spp), so the counter-RNG
+ * streams are disjoint and the N-device image equals the 1-device image up to fp32 summation order.  The scene is
+ * replicated; the only exchange step is ONE ncclReduce(sum, float, width*height*3) onto the first device over
+ * xGMI.  RCCL is loaded at run time by rt_multi_create (RT_ERR_RCCL if it is missing). */
+typedef struct rt_multi rt_multi;
+
+typedef struct rt_multi_stats {
+    uint64_t rays_traced; /* all devices */
+    uint64_t samples;     /* width*height*spp */
+    float kernel_ms;      /* slowest device's path-trace kernel time */
+    float reduce_ms;      /* the RCCL reduce, events on the root device's stream */
+    uint32_t n_devices;
+    uint32_t reserved;
+    float device_kernel_ms[RT_MAX_DEVICES];
+} rt_multi_stats;
+
+/* Contiguous split of sample indices [0, total_spp) into n_parts: the remainder goes to the lowest parts; a part
+ * may get 0 samples when total_spp < n_parts.  Pure arithmetic (no device needed). */
+int rt_partition_spp(uint32_t total_spp, uint32_t n_parts, uint32_t part, uint32_t* first, uint32_t* count);
+
+/* One rt_ctx per listed device + one RCCL communicator over them (ncclCommInitAll); device_ordinals[0] is the
+ * reduce root.  Replaces nothing in the reference. */
+int rt_multi_create(const int* device_ordinals, int n_devices, rt_multi** out);
+void rt_multi_destroy(rt_multi* m);
+const char* rt_multi_last_error(const rt_multi* m); /* m may be NULL: last create error */
+int rt_multi_upload_scene(rt_multi* m, const rt_scene* scene);
+/* rt_render over all devices: out_rgb as for rt_render (HOST, linear radiance mean over params->spp samples). */
+int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* params, float* out_rgb,
+                    rt_multi_stats* stats);
 
 /* ---- adjacent: `Screen::encode` screen.rs:26-45 ----------- */
 /* Gamma-2 + 0RGB packing of a HOST rgb buffer on the device.  Returns the number

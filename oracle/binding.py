@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liboracle.so")
+LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # env override: the sanitizer build
 
 orc_hit_dtype = np.dtype([("hit", "<i4"), ("sphere_id", "<i4"), ("material_id", "<i4"), ("front_face", "<i4"),
                           ("t", "<f8"), ("point", "<f8", 3), ("normal", "<f8", 3), ("margin", "<f8")])

@@ -26,6 +26,8 @@ RT_ERR_SCENE_TOO_LARGE = -3
 RT_ERR_NO_SCENE = -4
 RT_ERR_NO_DEVICE = -5
 RT_ERR_ALLOC = -6
+RT_ERR_RCCL = -7
+RT_MAX_DEVICES = 16
 
 RT_MAT_LAMBERTIAN, RT_MAT_METAL, RT_MAT_DIELECTRIC = 0, 1, 2
 RT_TEX_SOLID, RT_TEX_CHECKER, RT_TEX_VALUE_NOISE, RT_TEX_PERLIN_NOISE = 0, 1, 2, 3
@@ -90,6 +92,13 @@ class Stats(C.Structure):
     ]
 
 
+class MultiStats(C.Structure):
+    _fields_ = [
+        ("rays_traced", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float), ("reduce_ms", C.c_float),
+        ("n_devices", C.c_uint32), ("reserved", C.c_uint32), ("device_kernel_ms", C.c_float * RT_MAX_DEVICES),
+    ]
+
+
 # numpy views of the batch PODs
 ray_dtype = np.dtype([("origin", "<f4", 3), ("dir", "<f4", 3), ("time", "<f4")])
 hit_dtype = np.dtype([("hit", "<i4"), ("sphere_id", "<i4"), ("material_id", "<i4"), ("front_face", "<i4"),
@@ -102,7 +111,8 @@ assert ray_dtype.itemsize == 28 and hit_dtype.itemsize == 44 and scatter_dtype.i
 ABI_SYMBOLS = [
     "rt_create", "rt_destroy", "rt_last_error", "rt_abi_version", "rt_upload_scene", "rt_render",
     "rt_render_accum_device", "rt_render_accum_device_noalloc", "rt_intersect_batch", "rt_scatter_batch", "rt_texture_batch", "rt_camera_rays",
-    "rt_rng_batch", "rt_encode", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
+    "rt_rng_batch", "rt_encode", "rt_partition_spp", "rt_multi_create", "rt_multi_destroy", "rt_multi_last_error",
+    "rt_multi_upload_scene", "rt_multi_render", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
     "rt_debug_set_work_units", "rt_debug_set_scan_order",
@@ -152,6 +162,14 @@ def load() -> C.CDLL:
     lib.rt_camera_rays.argtypes = [vp, C.POINTER(Camera), vp, vp, C.c_uint32, vp]
     lib.rt_rng_batch.argtypes = [vp, C.c_uint64, vp, C.c_uint32, vp]
     lib.rt_encode.argtypes = [vp, vp, C.c_uint32, vp, u32p]
+    lib.rt_partition_spp.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32, u32p, u32p]
+    lib.rt_multi_create.argtypes = [C.POINTER(C.c_int), C.c_int, C.POINTER(vp)]
+    lib.rt_multi_destroy.argtypes = [vp]
+    lib.rt_multi_destroy.restype = None
+    lib.rt_multi_last_error.argtypes = [vp]
+    lib.rt_multi_last_error.restype = C.c_char_p
+    lib.rt_multi_upload_scene.argtypes = [vp, C.POINTER(Scene)]
+    lib.rt_multi_render.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(MultiStats)]
     lib.rth_world_create.argtypes = [C.c_char_p, C.c_int, C.c_uint64, C.c_double, C.POINTER(vp)]
     lib.rth_world_destroy.argtypes = [vp]
     lib.rth_world_destroy.restype = None
@@ -195,13 +213,19 @@ class World:
         self._h = h
         self.name = name
 
+    # The structs returned below are VIEWS into memory the rth_world owns: each view keeps a reference to this
+    # World, so `ctx.upload(api.World(..).scene)` cannot free the world before the upload has read it.
     @property
     def scene(self) -> Scene:
-        return load().rth_world_scene(self._h).contents
+        s = load().rth_world_scene(self._h).contents
+        s._world = self
+        return s
 
     @property
     def camera(self) -> Camera:
-        return load().rth_world_camera(self._h).contents
+        c = load().rth_world_camera(self._h).contents
+        c._world = self
+        return c
 
     @property
     def render_seed(self) -> int:
@@ -289,6 +313,52 @@ def make_params(width, height, spp, max_depth=100, antialias=True, seed=0, spp_o
 
 def _ptr(a: np.ndarray):
     return a.ctypes.data_as(C.c_void_p)
+
+
+def partition_spp(total_spp: int, n_parts: int, part: int):
+    """rt_partition_spp: (first sample index, count) of `part` (pure arithmetic, no device)."""
+    first, count = C.c_uint32(0), C.c_uint32(0)
+    rc = load().rt_partition_spp(total_spp, n_parts, part, C.byref(first), C.byref(count))
+    if rc != RT_OK:
+        raise RtError(rc, "bad partition arguments")
+    return int(first.value), int(count.value)
+
+
+class MultiContext:
+    """An rt_multi: one process, several GPUs of one node, spp-partitioned render + one RCCL reduce."""
+
+    def __init__(self, devices: Sequence[int]):
+        self.lib = load()
+        h = C.c_void_p()
+        arr = (C.c_int * len(devices))(*devices)
+        rc = self.lib.rt_multi_create(arr, len(devices), C.byref(h))
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_multi_last_error(None).decode())
+        self._h = h
+
+    def _check(self, rc):
+        if rc != RT_OK:
+            raise RtError(rc, self.lib.rt_multi_last_error(self._h).decode())
+
+    def upload(self, scene: Scene):
+        self._check(self.lib.rt_multi_upload_scene(self._h, C.byref(scene)))
+
+    def render(self, cam: Camera, params: Params):
+        out = np.empty((params.height, params.width, 3), np.float32)
+        st = MultiStats()
+        self._check(self.lib.rt_multi_render(self._h, C.byref(cam), C.byref(params), _ptr(out), C.byref(st)))
+        return out, st
+
+    def close(self):
+        if self._h:
+            self.lib.rt_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Context:

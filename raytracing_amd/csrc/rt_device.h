@@ -40,10 +40,26 @@ constexpr float kTwoPow32 = 4294967296.0f;
 
 struct DevTexture {
     rt_texture t;
-    float fractal_max;  // (1 - gain^layers) / (1 - gain), material.rs:189,216 (computed in f64 on upload)
-    float freq_turns;   // freq / 2pi (computed in f64 on upload): the checker needs only the SIGN of sin(freq * x)
-    int32_t pad[2];
+    float inv_fractal_max;  // (1 - gain) / (1 - gain^layers), material.rs:189,216 (computed in f64 on upload)
+    float freq_turns;       // freq / 2pi (computed in f64 on upload): the checker needs only the SIGN of sin(freq * x)
+    int32_t fused_id;       // noise textures: index of the FusedNoise image (table, kind) this texture reads
+    int32_t pad;
 };
+
+// What the noise kernels read, built on upload from an rt_noise_table for ONE noise kind and staged in LDS.
+// hash(x, y, z) = perms[perms[perms[x] + y] + z] (material.rs:309-313) followed by the corner term of that hash
+// value; the last lookup and the corner term are fused into one 16-byte entry indexed by i = perms[perms[x]+y]+z:
+//   Perlin  (material.rs:427-451): g[i] = {gx, gy, gz, 0}, the gradient of case perms[i] & 15 (TABLE, incl. its
+//                                  duplicated cases 9/11/15 = -y-z and 14 = -y+z), corner = g . (tx, ty, tz)
+//   value   (material.rs:339-347): g[i] = {0, 0, 0, randoms[perms[i]]}
+// so a corner costs one ds_read_b128 and three FMAs for either kind (the 16-way gradient switch was ~12 VALU
+// instructions per corner and a third dependent LDS level).
+struct FusedNoise {
+    uint16_t perms[512];  // all 512 entries are data (the second half is NOT perms[i & 255], material.rs:294-299)
+    float4 g[512];
+};
+static_assert(sizeof(FusedNoise) == 9216, "FusedNoise layout");
+constexpr int kMaxFused = 6;  // 6 x 9 KiB + the per-wave accumulators stay under the 64 KiB dynamic-LDS limit
 
 // Device view of an uploaded scene.
 // fp32 scan lists (read with scalar loads: wave-uniform index)
@@ -64,8 +80,8 @@ struct DevScene {
     const uint32_t* mat_id;
     const rt_material* mats;
     const DevTexture* texs;
-    const rt_noise_table* tables;
-    int32_t n_tables;
+    const FusedNoise* fused;  // n_fused images, copied to LDS by every workgroup that evaluates textures
+    int32_t n_fused;
     int32_t n_spheres;
     int32_t n_textures;
 };
@@ -80,21 +96,21 @@ __device__ __forceinline__ const RT_AS4 T* launder(const RT_AS4 T* p) {
     return p;
 }
 
-// LDS image: only the noise tables (gathered per lane, 24 dependent lookups per noise call).  The sphere
+// LDS image: only the fused noise tables (gathered per lane: 14 lookups per noise call).  The sphere
 // lists are NOT staged in LDS: they are wave-uniform and go through the scalar cache into SGPRs (see the scan).
 struct LdsScene {
-    const rt_noise_table* tables;
+    const FusedNoise* fused;
 };
 
-__host__ __device__ inline size_t lds_scene_bytes(int n_tables) { return (size_t)n_tables * sizeof(rt_noise_table); }
+__host__ __device__ inline size_t lds_scene_bytes(int n_fused) { return (size_t)n_fused * sizeof(FusedNoise); }
 
 __device__ inline LdsScene stage_scene(const DevScene& S, unsigned char* lds, int tid, int nthreads) {
     uint4* tab = reinterpret_cast<uint4*>(lds);
-    const uint4* gt = reinterpret_cast<const uint4*>(S.tables);
-    const int nt = S.n_tables * (int)(sizeof(rt_noise_table) / 16);
+    const uint4* gt = reinterpret_cast<const uint4*>(S.fused);
+    const int nt = S.n_fused * (int)(sizeof(FusedNoise) / 16);
     for (int i = tid; i < nt; i += nthreads) tab[i] = gt[i];
     __syncthreads();
-    return {reinterpret_cast<const rt_noise_table*>(tab)};
+    return {reinterpret_cast<const FusedNoise*>(tab)};
 }
 
 // ------------------------------------------------------------------ counter RNG
@@ -493,101 +509,133 @@ __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, c
 }
 
 // ------------------------------------------------------------------ textures
-__device__ __forceinline__ float lerpf(float t, float lo, float hi) { return lo * (1.0f - t) + hi * t; }  // lib.rs:46
-__device__ __forceinline__ float smoothf(float t) { return (t * t * t) * (t * (6.0f * t - 15.0f) + 10.0f); }  // lib.rs:50
+// Noise is evaluated for the TWO path slots of a lane at once, packed {slot 0, slot 1} like the scan: the float
+// arithmetic (frequency scale, fractions, quintic fades, the seven lerps, octave sums) is v_pk_*_f32, and the 14
+// dependent LDS lookups of the two slots are issued side by side, so their latencies overlap.  The texture is
+// wave-uniform inside noise_eval2 (callers loop over the distinct textures of a wave): its parameters are scalars.
+__device__ __forceinline__ f2 splat(float v) { return f2{v, v}; }
+__device__ __forceinline__ f2 smooth2(f2 t) {  // lib.rs:50: t^3 (t (6t - 15) + 10)
+    const f2 a = fma2(t, fma2(t, splat(6.0f), splat(-15.0f)), splat(10.0f));
+    return (t * t * t) * a;
+}
+__device__ __forceinline__ f2 lerp2(f2 t, f2 lo, f2 hi) { return fma2(t, hi - lo, lo); }  // lib.rs:46
 
-__device__ __forceinline__ int noise_hash(const rt_noise_table& tb, int x, int y, int z) {  // material.rs:309-313
-    return tb.perms[tb.perms[tb.perms[x] + y] + z];
-}
-__device__ __forceinline__ float perlin_grad(int h, float x, float y, float z) {  // material.rs:427-451 (the table)
-    h &= 15;
-    // first term: x for 0-7,12,13 else y (8,10 -> +y; 9,11,14,15 -> -y); second: y for 0-3,12,13 else z
-    const bool x_first = (h < 8) || h == 12 || h == 13;
-    const float a = x_first ? x : y;
-    const bool neg_a = x_first ? (h & 1) : !(h == 8 || h == 10);
-    const bool b_is_y = (h < 4) || h == 12 || h == 13;
-    const float b = b_is_y ? y : z;
-    bool neg_b;
-    if (h < 8) neg_b = (h & 2);
-    else if (h == 12 || h == 13) neg_b = false;
-    else neg_b = (h == 9 || h == 10 || h == 11 || h == 15);  // 8:+z 9:-z 10:-z 11:-z 14:+z 15:-z
-    return (neg_a ? -a : a) + (neg_b ? -b : b);
-}
-__device__ inline float noise_base(const rt_texture& tx, const rt_noise_table& tb, f3 p) {
-    p = p * tx.freq;
-    const float fx = floorf(p.x), fy = floorf(p.y), fz = floorf(p.z);
-    const float tx0 = p.x - fx, ty0 = p.y - fy, tz0 = p.z - fz;
-    const float sx = smoothf(tx0), sy = smoothf(ty0), sz = smoothf(tz0);
-    const int x0 = (int)fx & 255, y0 = (int)fy & 255, z0 = (int)fz & 255;
+// the eight corner terms of one slot: hash chain (material.rs:309-313) + fused corner entry
+__device__ __forceinline__ void noise_corners(const FusedNoise& tb, float fx, float fy, float fz, float tx, float ty,
+                                              float tz, float (&c)[8]) {
+    const int x0 = (int)fx & 255, y0 = (int)fy & 255, z0 = (int)fz & 255;  // material.rs:330-335
     const int x1 = (x0 + 1) & 255, y1 = (y0 + 1) & 255, z1 = (z0 + 1) & 255;
-    float v000, v100, v010, v110, v001, v101, v011, v111;
-    if (tx.kind == RT_TEX_VALUE_NOISE) {  // material.rs:339-347
-        v000 = tb.randoms[noise_hash(tb, x0, y0, z0)]; v100 = tb.randoms[noise_hash(tb, x1, y0, z0)];
-        v010 = tb.randoms[noise_hash(tb, x0, y1, z0)]; v110 = tb.randoms[noise_hash(tb, x1, y1, z0)];
-        v001 = tb.randoms[noise_hash(tb, x0, y0, z1)]; v101 = tb.randoms[noise_hash(tb, x1, y0, z1)];
-        v011 = tb.randoms[noise_hash(tb, x0, y1, z1)]; v111 = tb.randoms[noise_hash(tb, x1, y1, z1)];
-    } else {  // material.rs:482-504
-        const float tx1 = tx0 - 1.0f, ty1 = ty0 - 1.0f, tz1 = tz0 - 1.0f;
-        v000 = perlin_grad(noise_hash(tb, x0, y0, z0), tx0, ty0, tz0);
-        v100 = perlin_grad(noise_hash(tb, x1, y0, z0), tx1, ty0, tz0);
-        v010 = perlin_grad(noise_hash(tb, x0, y1, z0), tx0, ty1, tz0);
-        v110 = perlin_grad(noise_hash(tb, x1, y1, z0), tx1, ty1, tz0);
-        v001 = perlin_grad(noise_hash(tb, x0, y0, z1), tx0, ty0, tz1);
-        v101 = perlin_grad(noise_hash(tb, x1, y0, z1), tx1, ty0, tz1);
-        v011 = perlin_grad(noise_hash(tb, x0, y1, z1), tx0, ty1, tz1);
-        v111 = perlin_grad(noise_hash(tb, x1, y1, z1), tx1, ty1, tz1);
-    }
-    const float x00 = lerpf(sx, v000, v100), x10 = lerpf(sx, v010, v110);
-    const float x01 = lerpf(sx, v001, v101), x11 = lerpf(sx, v011, v111);
-    const float ya = lerpf(sy, x00, x10), yb = lerpf(sy, x01, x11);
-    const float n = lerpf(sz, ya, yb);
-    return tx.kind == RT_TEX_VALUE_NOISE ? n : (n + 1.0f) * 0.5f;
+    const int a0 = tb.perms[x0], a1 = tb.perms[x1];
+    const int b00 = tb.perms[a0 + y0], b10 = tb.perms[a1 + y0], b01 = tb.perms[a0 + y1], b11 = tb.perms[a1 + y1];
+    const float ux = tx - 1.0f, uy = ty - 1.0f, uz = tz - 1.0f;  // material.rs:478-479
+    auto corner = [&](int i, float x, float y, float z) {
+        const float4 g = tb.g[i];
+        return fmaf(g.z, z, fmaf(g.y, y, fmaf(g.x, x, g.w)));
+    };
+    c[0] = corner(b00 + z0, tx, ty, tz); c[1] = corner(b10 + z0, ux, ty, tz);   // 000 100
+    c[2] = corner(b01 + z0, tx, uy, tz); c[3] = corner(b11 + z0, ux, uy, tz);   // 010 110
+    c[4] = corner(b00 + z1, tx, ty, uz); c[5] = corner(b10 + z1, ux, ty, uz);   // 001 101
+    c[6] = corner(b01 + z1, tx, uy, uz); c[7] = corner(b11 + z1, ux, uy, uz);   // 011 111
 }
-__device__ inline float noise_eval(const DevTexture& T, const rt_noise_table* tables, f3 p) {
-    const rt_texture& tx = T.t;
-    const rt_noise_table& tb = tables[tx.table_id];
-    float v;
-    if (tx.op == RT_NOISE_PLAIN) {
-        v = noise_base(tx, tb, p);
+// noise(p) of material.rs:322-361 (value) / :466-521 (Perlin) for both slots; `perlin` is wave-uniform
+__device__ __forceinline__ f2 noise_base2(const FusedNoise& tb, float freq, bool perlin, f2 px, f2 py, f2 pz) {
+    px = px * freq; py = py * freq; pz = pz * freq;
+    const f2 fx = {floorf(px.x), floorf(px.y)}, fy = {floorf(py.x), floorf(py.y)}, fz = {floorf(pz.x), floorf(pz.y)};
+    const f2 tx = px - fx, ty = py - fy, tz = pz - fz;
+    float c0[8], c1[8];
+    noise_corners(tb, fx.x, fy.x, fz.x, tx.x, ty.x, tz.x, c0);
+    noise_corners(tb, fx.y, fy.y, fz.y, tx.y, ty.y, tz.y, c1);
+    const f2 sx = smooth2(tx), sy = smooth2(ty), sz = smooth2(tz);
+    const f2 x00 = lerp2(sx, f2{c0[0], c1[0]}, f2{c0[1], c1[1]}), x10 = lerp2(sx, f2{c0[2], c1[2]}, f2{c0[3], c1[3]});
+    const f2 x01 = lerp2(sx, f2{c0[4], c1[4]}, f2{c0[5], c1[5]}), x11 = lerp2(sx, f2{c0[6], c1[6]}, f2{c0[7], c1[7]});
+    const f2 n = lerp2(sz, lerp2(sy, x00, x10), lerp2(sy, x01, x11));
+    return perlin ? fma2(n, splat(0.5f), splat(0.5f)) : n;  // material.rs:520: (noise + 1) / 2
+}
+// eval(p): the NoiseAdapter callbacks as data (material.rs:184-263); T is wave-uniform
+template <class TexT>
+__device__ __forceinline__ f2 noise_eval2(const TexT& T, const FusedNoise* lds_fused, f2 px, f2 py, f2 pz) {
+    const FusedNoise& tb = lds_fused[T.fused_id];
+    const bool perlin = T.t.kind == RT_TEX_PERLIN_NOISE;
+    const float freq = T.t.freq;
+    f2 v;
+    if (T.t.op == RT_NOISE_PLAIN) {
+        v = noise_base2(tb, freq, perlin, px, py, pz);
     } else {  // material.rs:192-203, :219-233
-        float sum = 0.0f, amp = 1.0f;
-        f3 q = p;
-        for (int l = 0; l < tx.layers; ++l) {
-            float nz = noise_base(tx, tb, q);
-            if (tx.op == RT_NOISE_TURBULENCE) nz = fabsf(2.0f * nz - 1.0f);
-            sum += nz * amp;
-            q = q * tx.lacunarity;
-            amp *= tx.gain;
+        const bool turb = T.t.op == RT_NOISE_TURBULENCE;
+        const float lac = T.t.lacunarity, gain = T.t.gain;
+        f2 sum = splat(0.0f), qx = px, qy = py, qz = pz;
+        float amp = 1.0f;
+        for (int l = 0; l < T.t.layers; ++l) {
+            f2 nz = noise_base2(tb, freq, perlin, qx, qy, qz);
+            if (turb) { nz = fma2(nz, splat(2.0f), splat(-1.0f)); nz = f2{fabsf(nz.x), fabsf(nz.y)}; }
+            sum = fma2(nz, splat(amp), sum);
+            qx = qx * lac; qy = qy * lac; qz = qz * lac;
+            amp *= gain;
         }
-        v = sum / T.fractal_max;
+        v = sum * T.inv_fractal_max;
     }
-    if (tx.marbled) {  // material.rs:252-259
-        float n = tx.marble_gain * v + p.z;
-        n = tx.sin_freq * n + tx.phase;
-        v = (sinf(n) + 1.0f) * 0.5f;
+    if (T.t.marbled) {  // material.rs:252-259: (sin(sf * (g * v + p.z) + ph) + 1) / 2
+        f2 n = fma2(splat(T.t.marble_gain), v, pz);
+        n = fma2(splat(T.t.sin_freq), n, splat(T.t.phase));
+        // v_sin_f32 takes turns and wants them reduced: fract first.  ~1e-6 absolute, against a value that is
+        // no better known than fp32 knows sf * (...) (6e-8 relative of up to thousands of radians)
+        n = n * 0.15915494309189535f;
+        const float s0 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(n.x));
+        const float s1 = __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(n.y));
+        v = fma2(f2{s0, s1}, splat(0.5f), splat(0.5f));
     }
     return v;
 }
-// kNoise = false compiles the noise textures out: the render kernel is instantiated both ways and the scenes
-// without a noise texture (upload knows) run the variant whose register budget is not set by Perlin code.
-template <bool kNoise = true>
-__device__ inline f3 texture_value(const DevScene& S, const rt_noise_table* lds_tables, int tex_id, f3 p) {
+// The noise values of a lane's two texture requests (tex < 0: none).  Lanes of a wave may ask for different
+// textures: the loop runs once per DISTINCT texture of the wave (every reference scene has one), with that
+// texture's descriptor read through the scalar cache.
+__device__ __forceinline__ void noise_pair(const DevScene& S, const FusedNoise* lds_fused, int tex0, int tex1, f3 p0,
+                                           f3 p1, float& v0, float& v1) {
+    typedef const RT_AS4 DevTexture* TexPtr;
+    const TexPtr texs = (TexPtr)(uintptr_t)S.texs;
+    for (;;) {
+        const int want = tex0 >= 0 ? tex0 : tex1;
+        const unsigned long long m = __ballot(want >= 0);
+        if (m == 0ull) break;
+        const int cur = __builtin_amdgcn_readlane(want, (int)__ffsll((long long)m) - 1);
+        const bool m0 = tex0 == cur, m1 = tex1 == cur;
+        if (m0 || m1) {
+            const TexPtr T = texs + cur;
+            const f2 px = {m0 ? p0.x : 0.0f, m1 ? p1.x : 0.0f}, py = {m0 ? p0.y : 0.0f, m1 ? p1.y : 0.0f},
+                     pz = {m0 ? p0.z : 0.0f, m1 ? p1.z : 0.0f};
+            const f2 v = noise_eval2(*T, lds_fused, px, py, pz);
+            if (m0) { v0 = v.x; tex0 = -1; }
+            if (m1) { v1 = v.y; tex1 = -1; }
+        }
+    }
+}
+// Texture::value (material.rs:125-127) without the noise kinds: returns true and the colour for a solid or a
+// checker, false for a noise texture (the caller batches those through noise_pair).
+__device__ __forceinline__ bool texture_simple(const DevScene& S, int tex_id, f3 p, f3& out) {
+    // straight-line on purpose (every lane reads both colours of its descriptor and selects): no per-lane pointer
+    // selects, no divergent control flow in the middle of scatter
     const DevTexture& T = S.texs[tex_id];
     const int kind = T.t.kind;
-    if (kind == RT_TEX_SOLID) return {T.t.color_a[0], T.t.color_a[1], T.t.color_a[2]};
-    if (kind == RT_TEX_CHECKER) {  // material.rs:155-165
-        // sin(f x) < 0  <=>  fract(f x / 2pi) > 1/2 : one multiply and v_fract_f32 per axis instead of three libm
-        // sinf (range reduction + polynomial); the argument f*x is no better known in fp32 than this phase is
-        const float ft = T.freq_turns;
-        bool parity = __builtin_amdgcn_fractf(p.x * ft) > 0.5f;
-        parity ^= __builtin_amdgcn_fractf(p.y * ft) > 0.5f;
-        parity ^= __builtin_amdgcn_fractf(p.z * ft) > 0.5f;
-        const float* c = parity ? T.t.color_a : T.t.color_b;
-        return {c[0], c[1], c[2]};
-    }
-    if (!kNoise) return {0.0f, 0.0f, 0.0f};  // unreachable: this variant is only launched for noise-free scenes
-    const float v = noise_eval(T, lds_tables, p);
-    return {v, v, v};
+    // material.rs:155-165.  sin(f x) < 0  <=>  fract(f x / 2pi) > 1/2 : one multiply and v_fract_f32 per axis
+    // instead of three libm sinf (range reduction + polynomial); the argument f*x is no better known in fp32 than
+    // this phase is
+    const float ft = T.freq_turns;
+    bool parity = __builtin_amdgcn_fractf(p.x * ft) > 0.5f;
+    parity ^= __builtin_amdgcn_fractf(p.y * ft) > 0.5f;
+    parity ^= __builtin_amdgcn_fractf(p.z * ft) > 0.5f;
+    const bool a = kind == RT_TEX_SOLID || parity;  // SOLID: color_a; CHECKER: odd (color_a) / even (color_b)
+    out = {a ? T.t.color_a[0] : T.t.color_b[0], a ? T.t.color_a[1] : T.t.color_b[1], a ? T.t.color_a[2] : T.t.color_b[2]};
+    return kind == RT_TEX_SOLID || kind == RT_TEX_CHECKER;
+}
+// one texture for one point (the batch kernels); tex_id < 0: no texture (returns 0).  Every lane of the wave
+// must call it (noise_pair is a wave-level loop).
+__device__ inline f3 texture_value(const DevScene& S, const FusedNoise* lds_fused, int tex_id, f3 p) {
+    f3 c = {0.0f, 0.0f, 0.0f};
+    int noise_tex = -1;
+    if (tex_id >= 0 && !texture_simple(S, tex_id, p, c)) noise_tex = tex_id;
+    float v = 0.0f, unused = 0.0f;
+    noise_pair(S, lds_fused, noise_tex, -1, p, p, v, unused);
+    return noise_tex >= 0 ? f3{v, v, v} : c;  // colour = white * value (material.rs:369-373, :529-533)
 }
 
 // ------------------------------------------------------------------ materials
@@ -604,13 +652,17 @@ __device__ __forceinline__ float schlick(float cosv, float eta) {  // material.r
 // Material::scatter with explicit uniforms u0,u1.  Returns the albedo; `r` becomes the scattered ray.
 // Lanes of a wave hold different materials, so the three branches usually all run: what they share (the unit
 // incident direction, the unit-sphere sample) is computed once outside them.
+// A Lambertian whose texture is a noise texture returns white and its texture id in `noise_tex` (else -1): the
+// caller evaluates the noise at r.o (= the hit point) for both path slots together (noise_pair) and multiplies.
+// kNoise = false compiles that out: the render kernel is instantiated both ways and the scenes without a noise
+// texture (upload knows) run the variant whose register budget is not set by the noise code.
 template <bool kNoise = true>
-__device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables, const HitRec& h, Ray& r, float u0,
-                             float u1) {
+__device__ inline f3 scatter(const DevScene& S, const HitRec& h, Ray& r, float u0, float u1, int& noise_tex) {
     const rt_material m = S.mats[S.mat_id[h.sphere]];
     const f3 ud = normalize(r.d);
     const float dn = dot(ud, h.n);
     f3 albedo, dir;
+    noise_tex = -1;
     if (m.type == RT_MAT_DIELECTRIC) {  // material.rs:91-111
         const float eta = h.front ? fast_rcp(m.ior) : m.ior;
         const float cos_t = fminf(-dn, 1.0f);
@@ -628,7 +680,10 @@ __device__ inline f3 scatter(const DevScene& S, const rt_noise_table* lds_tables
         if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
             dir = h.n + sph;
             if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard (deviations)
-            albedo = texture_value<kNoise>(S, lds_tables, m.texture_id, h.p);
+            if (!texture_simple(S, m.texture_id, h.p, albedo)) {
+                albedo = {1.0f, 1.0f, 1.0f};
+                if (kNoise) noise_tex = m.texture_id;  // unreachable otherwise: that variant only runs noise-free scenes
+            }
         } else {  // material.rs:61-72
             const f3 fz = sph * m.fuzz;
             dir = reflect_unit(ud, h.n) + fz;

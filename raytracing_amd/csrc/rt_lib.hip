@@ -3,6 +3,8 @@
 //
 // Replaces reference main.rs:64-92 (rayon pixel/sample loop) + main.rs:110-139 (ray_color).
 #include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and enums only: the functions are resolved with dlsym when rt_multi_create is called
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -155,6 +157,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         // the camera sample of a fresh item (dim 0) or the scatter of the hit found in the previous pass
         // (dim 2 + depth).  A wave pays for a call whenever any lane needs one, so merging the two call sites
         // halves the Philox work per pass (it is half of everything outside the scan).
+        int noise_tex[2] = {-1, -1};  // noise textures whose value this pass still owes the slots' throughputs
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
@@ -197,11 +200,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                     P.alive = true;
                     P.orphan = false;
                 } else {  // the path hit h[s] in the previous pass and goes on (main.rs:117-125)
-                    const f3 albedo = scatter<kNoise>(A.S, L.tables, h[s], P.ray, u01(r[0]), u01(r[1]));
+                    const f3 albedo = scatter<kNoise>(A.S, h[s], P.ray, u01(r[0]), u01(r[1]), noise_tex[s]);
                     P.thr = P.thr * albedo;  // main.rs:118
                     ++P.depth;
                 }
             }
+        }
+        if (kNoise) {  // the two slots' noise textures in one packed evaluation at the hit points (= the new ray origins)
+            float v0 = 1.0f, v1 = 1.0f;
+            noise_pair(A.S, L.fused, noise_tex[0], noise_tex[1], ps[0].ray.o, ps[1].ray.o, v0, v1);
+            ps[0].thr = ps[0].thr * v0;  // colour = white * value (material.rs:369-373, :529-533)
+            ps[1].thr = ps[1].thr * v1;
         }
         if (__ballot(ps[0].alive || ps[1].alive) == 0ull) {
             if (!more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
@@ -262,6 +271,11 @@ __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, fl
     if (i < n) out[i] = (float)((double)accum[i] * scale);
 }
 
+__global__ void scale_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float scale) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[i] * scale;
+}
+
 // ---- fixed-batch kernels (parity entry points) --------------------------------------------
 __device__ inline void store_hit(const DevScene& S, const HitRec& h, rt_hit* out) {
     rt_hit o;
@@ -298,27 +312,39 @@ __global__ __launch_bounds__(kBlock) void scatter_batch_kernel(const DevScene S,
     extern __shared__ __align__(16) unsigned char lds[];
     const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
     rt_scatter o;
     memset(&o, 0, sizeof(o));
-    const rt_hit hq = hits[i];
-    if (hq.hit) {
-        const rt_ray q = rays[i];
-        Ray r = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time};
-        HitRec h;
-        h.sphere = hq.sphere_id;
-        h.front = hq.front_face;
-        h.t = hq.t;
-        h.p = {hq.point[0], hq.point[1], hq.point[2]};
-        h.n = {hq.normal[0], hq.normal[1], hq.normal[2]};
-        const f3 a = scatter(S, L.tables, h, r, u4[4 * i], u4[4 * i + 1]);
+    int noise_tex = -1;
+    Ray r = {{0, 0, 0}, {0, 0, 1}, 0};
+    f3 a = {0, 0, 0};
+    bool hit = false;
+    if (i < n) {
+        const rt_hit hq = hits[i];
+        hit = hq.hit != 0;
+        if (hit) {
+            const rt_ray q = rays[i];
+            r = {{q.origin[0], q.origin[1], q.origin[2]}, {q.dir[0], q.dir[1], q.dir[2]}, q.time};
+            HitRec h;
+            h.sphere = hq.sphere_id;
+            h.front = hq.front_face;
+            h.t = hq.t;
+            h.p = {hq.point[0], hq.point[1], hq.point[2]};
+            h.n = {hq.normal[0], hq.normal[1], hq.normal[2]};
+            a = scatter(S, h, r, u4[4 * i], u4[4 * i + 1], noise_tex);
+        }
+    }
+    // noise albedos: a wave-level loop, so every lane gets here (no early return above)
+    float v = 1.0f, unused = 1.0f;
+    noise_pair(S, L.fused, noise_tex, -1, r.o, r.o, v, unused);
+    if (noise_tex >= 0) a = {v, v, v};
+    if (hit) {
         o.scattered = 1;
         o.albedo[0] = a.x; o.albedo[1] = a.y; o.albedo[2] = a.z;
         o.origin[0] = r.o.x; o.origin[1] = r.o.y; o.origin[2] = r.o.z;
         o.dir[0] = r.d.x; o.dir[1] = r.d.y; o.dir[2] = r.d.z;
         o.time = r.time;
     }
-    out[i] = o;
+    if (i < n) out[i] = o;
 }
 
 __global__ __launch_bounds__(kBlock) void texture_batch_kernel(const DevScene S, int tex_id,
@@ -327,9 +353,11 @@ __global__ __launch_bounds__(kBlock) void texture_batch_kernel(const DevScene S,
     extern __shared__ __align__(16) unsigned char lds[];
     const LdsScene L = stage_scene(S, lds, threadIdx.x, kBlock);
     const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const f3 c = texture_value(S, L.tables, tex_id, {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]});
-    out3[3 * i] = c.x; out3[3 * i + 1] = c.y; out3[3 * i + 2] = c.z;
+    const bool live = i < n;
+    f3 p = {0, 0, 0};
+    if (live) p = {p3[3 * i], p3[3 * i + 1], p3[3 * i + 2]};
+    const f3 c = texture_value(S, L.fused, live ? tex_id : -1, p);
+    if (live) { out3[3 * i] = c.x; out3[3 * i + 1] = c.y; out3[3 * i + 2] = c.z; }
 }
 
 __global__ void camera_rays_kernel(const rt_camera cam, const float* __restrict__ ij, const float* __restrict__ u4,
@@ -442,6 +470,22 @@ struct TmpBuf {  // device scratch for the batch entry points
 
 size_t align16(size_t v) { return (v + 15) & ~(size_t)15; }
 
+// FusedNoise image of one noise table for one kind (rt_device.h).  The gradient of hash value h is the TABLE of
+// material.rs:431-450, case h & 15 (cases 9, 11 and 15 are all -y-z and 14 is -y+z there: reproduced, not "fixed").
+void build_fused(const rt_noise_table& tb, bool perlin, FusedNoise& out) {
+    static const float kGrad[16][3] = {
+        {1, 1, 0}, {-1, 1, 0}, {1, -1, 0}, {-1, -1, 0},   // 0-3:   +-x +-y
+        {1, 0, 1}, {-1, 0, 1}, {1, 0, -1}, {-1, 0, -1},   // 4-7:   +-x +-z
+        {0, 1, 1}, {0, -1, -1}, {0, 1, -1}, {0, -1, -1},  // 8-11:  y+z, -y-z, y-z, -y-z
+        {1, 1, 0}, {-1, 1, 0}, {0, -1, 1}, {0, -1, -1}};  // 12-15: x+y, -x+y, -y+z, -y-z
+    for (int i = 0; i < 512; ++i) {
+        out.perms[i] = tb.perms[i];
+        const int h = tb.perms[i];
+        if (perlin) out.g[i] = make_float4(kGrad[h & 15][0], kGrad[h & 15][1], kGrad[h & 15][2], 0.0f);
+        else out.g[i] = make_float4(0.0f, 0.0f, 0.0f, tb.randoms[h]);
+    }
+}
+
 int check_ready(rt_ctx* c) {
     if (!c) return RT_ERR_BAD_ARG;
     RT_HIP(c, hipSetDevice(c->device));
@@ -532,12 +576,19 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             return fail(c, RT_ERR_BAD_ARG, "Lambertian texture_id out of range");
         if (m.type == RT_MAT_DIELECTRIC && !(m.ior > 0.0f)) return fail(c, RT_ERR_BAD_ARG, "Dielectric ior must be > 0");
     }
+    for (uint32_t t = 0; t < s->n_noise_tables; ++t)
+        for (int i = 0; i < 512; ++i)
+            if (s->noise_tables[t].perms[i] > 255) return fail(c, RT_ERR_BAD_ARG, "noise perms entry > 255");
     std::vector<DevTexture> texs(s->n_textures);
+    std::vector<FusedNoise> fused;                  // one image per (noise table, kind) pair in use
+    std::vector<std::pair<int32_t, int32_t>> fused_key;
     for (uint32_t i = 0; i < s->n_textures; ++i) {
         const rt_texture& t = s->textures[i];
         if (t.kind < RT_TEX_SOLID || t.kind > RT_TEX_PERLIN_NOISE) return fail(c, RT_ERR_BAD_ARG, "unknown texture kind");
         texs[i].t = t;
-        texs[i].fractal_max = 1.0f;
+        texs[i].inv_fractal_max = 1.0f;
+        texs[i].fused_id = -1;
+        texs[i].pad = 0;
         texs[i].freq_turns = (float)((double)t.freq / 6.283185307179586476925);
         if (t.kind >= RT_TEX_VALUE_NOISE) {
             if (t.table_id < 0 || (uint32_t)t.table_id >= s->n_noise_tables) return fail(c, RT_ERR_BAD_ARG, "noise table_id out of range");
@@ -548,13 +599,20 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
                 if (!(0.0f < t.gain && t.gain < 1.0f)) return fail(c, RT_ERR_BAD_ARG, "fBm: Gain must be in range (0, 1).");
                 double g = t.gain, pw = 1.0;
                 for (int l = 0; l < t.layers; ++l) pw *= g;
-                texs[i].fractal_max = (float)((1.0 - pw) / (1.0 - g));
+                texs[i].inv_fractal_max = (float)((1.0 - g) / (1.0 - pw));
             }
+            const std::pair<int32_t, int32_t> key(t.table_id, t.kind);
+            size_t f = std::find(fused_key.begin(), fused_key.end(), key) - fused_key.begin();
+            if (f == fused_key.size()) {
+                if (fused.size() == (size_t)kMaxFused)
+                    return fail(c, RT_ERR_SCENE_TOO_LARGE, "more than 6 (noise table, noise kind) pairs in use: their LDS images do not fit");
+                fused_key.push_back(key);
+                fused.emplace_back();
+                build_fused(s->noise_tables[t.table_id], t.kind == RT_TEX_PERLIN_NOISE, fused.back());
+            }
+            texs[i].fused_id = (int32_t)f;
         }
     }
-    for (uint32_t t = 0; t < s->n_noise_tables; ++t)
-        for (int i = 0; i < 512; ++i)
-            if (s->noise_tables[t].perms[i] > 255) return fail(c, RT_ERR_BAD_ARG, "noise perms entry > 255");
 
     std::vector<float4> stat, mov_a, mov_b;
     std::vector<int32_t> stat_id, mov_id, big_id;
@@ -636,7 +694,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     }
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
-    const size_t lds_need = lds_scene_bytes((int)s->n_noise_tables);
+    const size_t lds_need = lds_scene_bytes((int)fused.size());
     if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
 
     free_scene(c);
@@ -659,12 +717,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, s->material_id, (size_t)s->n_spheres, &D.mat_id));
     UP(dev_copy(c, s->materials, (size_t)s->n_materials, &D.mats));
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
-    UP(dev_copy(c, s->noise_tables, (size_t)s->n_noise_tables, &D.tables));
+    UP(dev_copy(c, fused.data(), fused.size(), &D.fused));
 #undef UP
     D.lists.ns_pad = (int32_t)stat.size();
     D.lists.nm_pad = (int32_t)mov_a.size();
     D.n_big = (int32_t)big_id.size();
-    D.n_tables = (int32_t)s->n_noise_tables;
+    D.n_fused = (int32_t)fused.size();
     D.n_spheres = (int32_t)s->n_spheres;
     D.n_textures = (int32_t)s->n_textures;
     c->S = D;
@@ -977,6 +1035,202 @@ int rt_encode(rt_ctx* c, const float* rgb, uint32_t n_pixels, uint32_t* out_0rgb
     uint32_t cnt = 0;
     RT_HIP(c, hipMemcpy(&cnt, dcnt.p, sizeof(cnt), hipMemcpyDeviceToHost));
     if (n_invalid) *n_invalid = cnt;
+    return RT_OK;
+}
+
+}  // extern "C"
+
+
+// ---------------------------------------------------------------------------------- multi-device
+// One process, n devices: samples-per-pixel are partitioned over the devices (device g renders the sample indices
+// rt_partition_spp gives it, for every pixel: disjoint counter-RNG streams, scene replicated), then the fp32
+// radiance-sum buffers are summed onto the first device with ONE ncclReduce over xGMI.  RCCL is bound at run time
+// (dlopen) so that single-device callers do not need it installed.
+namespace {
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*Reduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load(std::string& err) {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"})
+            if ((lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL))) break;
+        if (!lib) { err = std::string("cannot load librccl: ") + dlerror(); return false; }
+#define RT_SYM(field, sym) \
+    if (!(field = reinterpret_cast<decltype(field)>(dlsym(lib, sym)))) { err = std::string("librccl lacks ") + sym; return false; }
+        RT_SYM(CommInitAll, "ncclCommInitAll") RT_SYM(CommDestroy, "ncclCommDestroy") RT_SYM(Reduce, "ncclReduce")
+        RT_SYM(GroupStart, "ncclGroupStart") RT_SYM(GroupEnd, "ncclGroupEnd") RT_SYM(GetErrorString, "ncclGetErrorString")
+#undef RT_SYM
+        return true;
+    }
+};
+Rccl g_rccl;
+thread_local std::string g_multi_create_error;
+}  // namespace
+
+struct rt_multi {
+    std::vector<rt_ctx*> ctx;      // one per device, in the caller's order; ctx[0] is the reduce root
+    std::vector<ncclComm_t> comm;
+    std::vector<float*> dsum;      // per device: W*H*3 radiance sums of its share
+    size_t dsum_cap = 0;
+    std::string err;
+};
+
+extern "C" {
+
+int rt_partition_spp(uint32_t total_spp, uint32_t n_parts, uint32_t part, uint32_t* first, uint32_t* count) {
+    if (!first || !count || n_parts == 0 || part >= n_parts) return RT_ERR_BAD_ARG;
+    const uint32_t base = total_spp / n_parts, rem = total_spp % n_parts;
+    *count = base + (part < rem ? 1u : 0u);          // the remainder goes to the lowest parts
+    *first = part * base + std::min(part, rem);
+    return RT_OK;
+}
+
+const char* rt_multi_last_error(const rt_multi* m) { return m ? m->err.c_str() : g_multi_create_error.c_str(); }
+
+void rt_multi_destroy(rt_multi* m) {
+    if (!m) return;
+    for (size_t i = 0; i < m->ctx.size(); ++i) {
+        if (m->ctx[i]) (void)hipSetDevice(m->ctx[i]->device);
+        if (i < m->comm.size() && m->comm[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm[i]);
+        if (i < m->dsum.size() && m->dsum[i]) (void)hipFree(m->dsum[i]);
+        rt_destroy(m->ctx[i]);
+    }
+    delete m;
+}
+
+int rt_multi_create(const int* device_ordinals, int n_devices, rt_multi** out) {
+    auto bad = [&](int code, const std::string& msg) { g_multi_create_error = msg; return code; };
+    if (!out) return bad(RT_ERR_BAD_ARG, "out is NULL");
+    *out = nullptr;
+    if (!device_ordinals || n_devices < 1 || n_devices > RT_MAX_DEVICES) return bad(RT_ERR_BAD_ARG, "need 1..RT_MAX_DEVICES device ordinals");
+    for (int i = 0; i < n_devices; ++i)
+        for (int j = 0; j < i; ++j)
+            if (device_ordinals[i] == device_ordinals[j]) return bad(RT_ERR_BAD_ARG, "a device ordinal is listed twice");
+    std::string err;
+    if (!g_rccl.load(err)) return bad(RT_ERR_RCCL, err);
+    rt_multi* m = new rt_multi();
+    m->ctx.assign(n_devices, nullptr);
+    m->comm.assign(n_devices, nullptr);
+    m->dsum.assign(n_devices, nullptr);
+    for (int i = 0; i < n_devices; ++i) {
+        const int rc = rt_create(device_ordinals[i], &m->ctx[i]);
+        if (rc != RT_OK) {
+            g_multi_create_error = std::string("device ") + std::to_string(device_ordinals[i]) + ": " + rt_last_error(nullptr);
+            rt_multi_destroy(m);
+            return rc;
+        }
+    }
+    const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, device_ordinals);  // rank i = device_ordinals[i]
+    if (r != ncclSuccess) {
+        g_multi_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
+        rt_multi_destroy(m);
+        return RT_ERR_RCCL;
+    }
+    *out = m;
+    return RT_OK;
+}
+
+int rt_multi_upload_scene(rt_multi* m, const rt_scene* scene) {
+    if (!m) return RT_ERR_BAD_ARG;
+    for (rt_ctx* c : m->ctx) {  // the scene (tens of KiB) is replicated
+        const int rc = rt_upload_scene(c, scene);
+        if (rc != RT_OK) { m->err = c ? c->err : "NULL ctx"; return rc; }
+    }
+    return RT_OK;
+}
+
+int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float* out_rgb, rt_multi_stats* stats) {
+    if (!m) return RT_ERR_BAD_ARG;
+    const int n = (int)m->ctx.size();
+    auto fail_from = [&](rt_ctx* c, int rc) { m->err = c->err; return rc; };
+    int rc = check_render_args(m->ctx[0], cam, p, out_rgb);
+    if (rc != RT_OK) return fail_from(m->ctx[0], rc);
+    const size_t n_el = (size_t)p->width * p->height * 3;
+    if (m->dsum_cap < n_el) {
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(m->ctx[i]->device);
+            if (m->dsum[i]) (void)hipFree(m->dsum[i]);
+            m->dsum[i] = nullptr;
+        }
+        m->dsum_cap = 0;
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(m->ctx[i]->device);
+            if (hipMalloc((void**)&m->dsum[i], n_el * sizeof(float)) != hipSuccess) {
+                m->err = "cannot allocate the per-device radiance sums";
+                return RT_ERR_ALLOC;
+            }
+        }
+        m->dsum_cap = n_el;
+    }
+    // 1. every device renders its share; all launches are queued before any is waited for
+    std::vector<rt_params> share(n, *p);
+    std::vector<uint32_t> launches(n, 0);
+    for (int i = 0; i < n; ++i) {
+        rt_ctx* c = m->ctx[i];
+        uint32_t first = 0, count = 0;
+        (void)rt_partition_spp(p->spp, (uint32_t)n, (uint32_t)i, &first, &count);
+        share[i].spp = count;
+        share[i].spp_offset = p->spp_offset + first;
+        if ((rc = check_ready(c)) != RT_OK) return fail_from(c, rc);
+        if (count == 0) {  // more devices than samples: this one contributes zeros to the sum
+            if (hipMemsetAsync(m->dsum[i], 0, n_el * sizeof(float), c->stream) != hipSuccess) { m->err = "hipMemsetAsync failed"; return RT_ERR_HIP; }
+            continue;
+        }
+        if ((rc = ensure_accum(c, n_el)) != RT_OK) return fail_from(c, rc);
+        if ((rc = render_launch(c, cam, &share[i], c->accum, c->rays, m->dsum[i], kFixedToFloat, &launches[i])) != RT_OK)
+            return fail_from(c, rc);
+    }
+    rt_multi_stats st;
+    std::memset(&st, 0, sizeof(st));
+    st.n_devices = (uint32_t)n;
+    st.samples = (uint64_t)p->width * p->height * p->spp;
+    for (int i = 0; i < n; ++i) {
+        rt_ctx* c = m->ctx[i];
+        if (share[i].spp == 0) {
+            (void)hipSetDevice(c->device);
+            if (hipStreamSynchronize(c->stream) != hipSuccess) { m->err = "hipStreamSynchronize failed"; return RT_ERR_HIP; }
+            continue;
+        }
+        rt_stats s1;
+        if ((rc = render_finish(c, &share[i], launches[i], &s1)) != RT_OK) return fail_from(c, rc);
+        st.rays_traced += s1.rays_traced;
+        st.kernel_ms = std::max(st.kernel_ms, s1.kernel_ms);
+        st.device_kernel_ms[i] = s1.kernel_ms;
+    }
+    // 2. the exchange step: one sum-reduce of W*H*3 floats onto ctx[0] (in place on the root)
+    rt_ctx* root = m->ctx[0];
+    (void)hipSetDevice(root->device);
+    if (hipEventRecord(root->ev0, root->stream) != hipSuccess) { m->err = "hipEventRecord failed"; return RT_ERR_HIP; }
+    ncclResult_t r = g_rccl.GroupStart();
+    for (int i = 0; i < n && r == ncclSuccess; ++i)
+        r = g_rccl.Reduce(m->dsum[i], m->dsum[i], n_el, ncclFloat, ncclSum, 0, m->comm[i], m->ctx[i]->stream);
+    const ncclResult_t r2 = g_rccl.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) { m->err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r); return RT_ERR_RCCL; }
+    (void)hipSetDevice(root->device);
+    if (hipEventRecord(root->ev1, root->stream) != hipSuccess) { m->err = "hipEventRecord failed"; return RT_ERR_HIP; }
+    // 3. mean over all samples on the root, back to the host
+    if (root->out_cap < n_el) {
+        if (root->out) (void)hipFree(root->out);
+        root->out = nullptr; root->out_cap = 0;
+        if (hipMalloc((void**)&root->out, n_el * sizeof(float)) != hipSuccess) { m->err = "cannot allocate the output image"; return RT_ERR_ALLOC; }
+        root->out_cap = n_el;
+    }
+    hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, root->stream, (const float*)m->dsum[0],
+                       root->out, n_el, (float)(1.0 / (double)p->spp));
+    for (int i = 0; i < n; ++i) {
+        (void)hipSetDevice(m->ctx[i]->device);
+        if (hipStreamSynchronize(m->ctx[i]->stream) != hipSuccess) { m->err = "hipStreamSynchronize failed after the reduce"; return RT_ERR_HIP; }
+    }
+    (void)hipSetDevice(root->device);
+    if (hipMemcpy(out_rgb, root->out, n_el * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { m->err = "hipMemcpy failed"; return RT_ERR_HIP; }
+    (void)hipEventElapsedTime(&st.reduce_ms, root->ev0, root->ev1);
+    if (stats) *stats = st;
     return RT_OK;
 }
 

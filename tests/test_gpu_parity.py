@@ -155,9 +155,13 @@ def test_textures_all_noise_scenes(ctx, api):
         err = np.abs(got - exp).max(1)
         if name in ("Random", "BirdsEyeView"):  # checker: exact colours unless sin() sits on a zero crossing
             assert (err[near] > 1e-6).sum() <= 2, name
+            assert (err[~near] > 1e-6).sum() <= 0.5 * (~near).sum(), name  # f*x ~ 1e4 rad: the phase itself is fp32-limited
         else:
-            tol = 2e-4 if "Marbled" not in name and "Turb" not in name and "Pink" not in name else 2e-3
-            assert err[near].max() < tol, (name, float(err[near].max()))
+            fractal = "Marbled" in name or "Turb" in name or "Pink" in name
+            # measured (round 2): near <= 3.2e-7 plain / 6.1e-6 fractal; far <= 1.2e-7 plain / 4.7e-4 fractal (the
+            # highest octave sits at lattice coordinates ~3e5, where an fp32 ulp is 3 % of a cell)
+            assert err[near].max() < (2e-5 if fractal else 2e-6), (name, float(err[near].max()))
+            assert err[~near].max() < (2e-3 if fractal else 2e-6), (name, float(err[~near].max()))
             assert np.all((got >= 0) & (got <= 1)), name
         print(name, "max err near", float(err[near].max()), "far", float(err[~near].max()))
     with pytest.raises(api.RtError):
@@ -238,6 +242,36 @@ def test_render_properties_full_size(ctx, api):
         with pytest.raises(api.RtError) as e:
             ctx.render(w.camera, api.make_params(kw["width"], kw["height"], kw["spp"], max_depth=kw["max_depth"]))
         assert e.value.code == api.RT_ERR_BAD_ARG
+
+
+@pytest.mark.parametrize("name,W,H,spp,off", [
+    ("Random", 1200, 800, 500, 0),             # BASELINE configs[2]: motion blur, 484 moving spheres
+    ("PerlinNoise2", 1200, 800, 500, 0),       # BASELINE configs[3]: noise / turbulence / marble
+    ("PerlinTurbulence", 1200, 800, 500, 0),
+    ("PerlinMarbled", 1200, 800, 500, 0),
+    ("FinalStatic", 3840, 2160, 512, 512),     # BASELINE configs[4]: one rank's share (rank 1 of 8) of 4096 spp at 4K
+])
+def test_baseline_configs_full_size_properties(ctx, api, name, W, H, spp, off):
+    """Every BASELINE config at its FULL size, through size-independent properties: the render is bit-reproducible,
+    every pixel is finite and in [0,1] (the reference's encode would panic otherwise, screen.rs:31-34), and it
+    equals the sum of its two spp halves rendered separately (the multi-GPU partition).  The 4K share is 4.2e9
+    samples and must cross the 2^31-sample launch split."""
+    w = api.World(name, seed=1, aspect=W / H)
+    ctx.upload(w.scene)
+    full, st = ctx.render(w.camera, api.make_params(W, H, spp, seed=w.render_seed, spp_offset=off))
+    assert st.samples == W * H * spp and st.n_launches == (2 if W * H * spp > 2**31 else 1)
+    assert np.isfinite(full).all() and full.min() >= 0 and full.max() <= 1
+    again, st2 = ctx.render(w.camera, api.make_params(W, H, spp, seed=w.render_seed, spp_offset=off))
+    assert st2.rays_traced == st.rays_traced and np.array_equal(full, again)
+    del again
+    h = spp // 2
+    lo, s0 = ctx.render(w.camera, api.make_params(W, H, h, seed=w.render_seed, spp_offset=off))
+    hi, s1 = ctx.render(w.camera, api.make_params(W, H, spp - h, seed=w.render_seed, spp_offset=off + h))
+    assert s0.rays_traced + s1.rays_traced == st.rays_traced
+    whole = (h * lo.astype(np.float64) + (spp - h) * hi.astype(np.float64)) / spp
+    assert np.abs(whole - full).max() < 2e-7
+    print(name, f"{W}x{H}@{spp}+{off}: kernel_ms {st.kernel_ms:.1f} launches {st.n_launches} rays/sample "
+                f"{st.rays_traced / st.samples:.3f} mean {full.mean():.4f}")
 
 
 def test_work_unit_size_does_not_change_the_image(ctx, api):

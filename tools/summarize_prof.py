@@ -30,7 +30,7 @@ def main():
     counters = {}
     out.append("\n## rocprofv3 --pmc passes (separate runs; per-kernel SUM over dispatches, and dispatch count)\n")
     out.append("| pass | kernel | counter | dispatches | sum | per dispatch |\n|---|---|---|---|---|---|")
-    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
+    for p in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_lds"):
         q = ("select kernel_name, counter_name, count(*), sum(value) from counters_collection "
              "group by kernel_name, counter_name")
         for k, c, n, s in rows(os.path.join(src, p, "pmc_results.db"), q):
@@ -44,8 +44,20 @@ def main():
         fetch = counters.get("FETCH_SIZE", 0.0) * 1024 * 2
         write = counters.get("WRITE_SIZE", 0.0) * 1024
         derived.append(f"HBM bytes per render_kernel launch: fetch {fetch:.4g} (x2-corrected) + write {write:.4g} = {fetch + write:.4g}")
-        json.dump({"bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
-                   "source": os.path.basename(src)}, open(os.path.join(os.path.dirname(dst), "hbm_traffic.json"), "w"))
+        # one entry per measured workload; bench.py only quotes the entry whose config matches its arguments
+        tpath = os.path.join(os.path.dirname(dst), "hbm_traffic.json")
+        try:
+            entries = json.load(open(tpath)).get("entries", [])
+        except Exception:
+            entries = []
+        cfg = {}
+        if os.path.exists(bench):
+            c = json.loads(open(bench).read().strip().splitlines()[-1])["config"]
+            cfg = {"scene": c["scene"], "width": c["width"], "height": c["height"], "spp": c["spp_per_gpu"]}
+        entries = [e for e in entries if e.get("config") != cfg]
+        entries.append({"config": cfg, "bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
+                        "source": os.path.basename(src)})
+        json.dump({"entries": entries}, open(tpath, "w"), indent=1)
     if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
         derived.append("VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)): "
                        f"{counters['SQ_THREAD_CYCLES_VALU'] / (64 * counters['SQ_ACTIVE_INST_VALU']):.3f}")
