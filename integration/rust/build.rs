@@ -9,15 +9,36 @@ fn main() {
     } else {
         let root = PathBuf::from(env::var("RTX_HIP_ROOT").expect("RTX_HIP_ROOT = path to the rtx_hip repo"));
         let hipcc = env::var("HIPCC").unwrap_or_else(|_| "/opt/rocm/bin/hipcc".into());
-        let status = Command::new(hipcc)
+        let flags = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off"];
+        // The scan's scalar prefetch is pinned by hand (rt_device.h: inline-asm s_load_dwordx16 whose destination SGPRs
+        // the compiler does not know are in flight).  As the repo's Makefile does: emit the ISA with the SAME flags and
+        // let tools/check_prefetch.py prove that nothing touches those SGPRs before the wait; fail the build otherwise.
+        let isa = out.join("rt_lib.s");
+        let status = Command::new(&hipcc)
+            .args(flags)
+            .args(["-S", "--cuda-device-only", "-o"])
+            .arg(&isa)
+            .arg(root.join("raytracing_amd/csrc/rt_lib.hip"))
+            .status()
+            .expect("running hipcc -S");
+        assert!(status.success(), "hipcc -S failed");
+        let status = Command::new("python3")
+            .arg(root.join("tools/check_prefetch.py"))
+            .arg(&isa)
+            .status()
+            .expect("running tools/check_prefetch.py (python3 needed; or build with -DRT_ASM_PREFETCH=0)");
+        assert!(status.success(), "check_prefetch found a clobbered prefetch: build with -DRT_ASM_PREFETCH=0");
+        let status = Command::new(&hipcc)
             // -ffp-contract=off is REQUIRED: a sample must not depend on which of a lane's two path slots ran it.
-            .args(["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=off", "-shared", "-o"])
+            .args(flags)
+            .args(["-shared", "-o"])
             .arg(out.join("librtx_hip.so"))
             .arg(root.join("raytracing_amd/csrc/rt_lib.hip"))
             .arg(root.join("raytracing_amd/csrc/host_scene.cpp"))
             .status()
             .expect("running hipcc");
         assert!(status.success(), "hipcc failed");
+        // the multi-device entry points bind librccl at run time (dlopen): nothing more to link here
         println!("cargo:rerun-if-changed={}", root.join("include/rtx_hip.h").display());
         println!("cargo:rerun-if-changed={}", root.join("raytracing_amd/csrc/rt_lib.hip").display());
         println!("cargo:rerun-if-changed={}", root.join("raytracing_amd/csrc/rt_device.h").display());

@@ -119,6 +119,27 @@ pub struct rt_stats {
     pub reserved: u32,
 }
 
+pub const RT_MAX_DEVICES: usize = 16;
+pub const RT_NOALLOC_MAX_PIXELS: u32 = 1 << 20;
+pub const RT_ERR_RCCL: c_int = -7;
+
+#[repr(C)]
+pub struct rt_multi {
+    _p: [u8; 0],
+}
+
+#[repr(C)]
+#[derive(Clone, Copy, Default)]
+pub struct rt_multi_stats {
+    pub rays_traced: u64,
+    pub samples: u64,
+    pub kernel_ms: f32, // slowest device
+    pub reduce_ms: f32, // the one ncclReduce over xGMI
+    pub n_devices: u32,
+    pub reserved: u32,
+    pub device_kernel_ms: [f32; RT_MAX_DEVICES],
+}
+
 extern "C" {
     pub fn rt_abi_version() -> c_int;
     pub fn rt_create(device: c_int, out: *mut *mut rt_ctx) -> c_int;
@@ -131,5 +152,35 @@ extern "C" {
         params: *const rt_params,
         out_rgb: *mut f32, // width*height*3, row-major, y = 0 is the top row, linear radiance means
         stats: *mut rt_stats,
+    ) -> c_int;
+    // per-pixel radiance SUMS into a DEVICE buffer (callers that manage device memory themselves)
+    pub fn rt_render_accum_device(
+        ctx: *mut rt_ctx,
+        cam: *const rt_camera,
+        params: *const rt_params,
+        d_sum_rgb: *mut f32,
+        stats: *mut rt_stats,
+    ) -> c_int;
+    // the same for callers that cannot allocate (workspace in a static device array, <= RT_NOALLOC_MAX_PIXELS pixels)
+    pub fn rt_render_accum_device_noalloc(
+        ctx: *mut rt_ctx,
+        cam: *const rt_camera,
+        params: *const rt_params,
+        d_sum_rgb: *mut f32,
+        stats: *mut rt_stats,
+    ) -> c_int;
+
+    // ---- one process, the GPUs of one node: spp-partitioned render + one RCCL sum-reduce onto devices[0]
+    pub fn rt_partition_spp(total_spp: u32, n_parts: u32, part: u32, first: *mut u32, count: *mut u32) -> c_int;
+    pub fn rt_multi_create(device_ordinals: *const c_int, n_devices: c_int, out: *mut *mut rt_multi) -> c_int;
+    pub fn rt_multi_destroy(m: *mut rt_multi);
+    pub fn rt_multi_last_error(m: *const rt_multi) -> *const c_char;
+    pub fn rt_multi_upload_scene(m: *mut rt_multi, scene: *const rt_scene) -> c_int;
+    pub fn rt_multi_render(
+        m: *mut rt_multi,
+        cam: *const rt_camera,
+        params: *const rt_params,
+        out_rgb: *mut f32,
+        stats: *mut rt_multi_stats,
     ) -> c_int;
 }

@@ -14,7 +14,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("ORACLE_LIB") or os.path.join(_HERE, "liboracle.so")  # env override: the sanitizer build
 
 orc_hit_dtype = np.dtype([("hit", "<i4"), ("sphere_id", "<i4"), ("material_id", "<i4"), ("front_face", "<i4"),
-                          ("t", "<f8"), ("point", "<f8", 3), ("normal", "<f8", 3), ("margin", "<f8")])
+                          ("t", "<f8"), ("point", "<f8", 3), ("normal", "<f8", 3), ("margin", "<f8"),
+                          ("margin_tie", "<f8")])
 orc_scatter_dtype = np.dtype([("scattered", "<i4"), ("pad", "<i4"), ("albedo", "<f8", 3), ("origin", "<f8", 3),
                               ("dir", "<f8", 3), ("time", "<f8")])
 orc_ray_dtype = np.dtype([("origin", "<f8", 3), ("dir", "<f8", 3), ("time", "<f8")])

@@ -13,7 +13,8 @@ typedef struct orc_hit {
     double t;
     double point[3];
     double normal[3];
-    double margin;  // >= 1: every hit/miss/id decision is safely away from flipping in fp32 (see below)
+    double margin;      // >= 1: every hit/miss/id decision is safely away from flipping in fp32 (see below)
+    double margin_tie;  // the same WITHOUT term (a), the discriminant band: only the t_min boundary and near-ties
 } orc_hit;
 
 typedef struct orc_scatter {
@@ -102,7 +103,9 @@ void orc_pcg_unit_disk(uint64_t seed, uint32_t n, double* out3) {
 //       closest hit.  (The r = 1000 ground is tested in f64 on the GPU, but it is held to the same rule.)
 //   (b) |t_root / t_min - 1| / 0.05 over the real roots of those spheres: a root sitting on the t_min boundary,
 //   (c) (t_2nd - t_best) * |d| / max(t_best * |d|, r_best) / 1e-3: closest vs runner-up near-tie.
-static double decision_margin(const Scene<double>& sc, const Ray<double>& ray, double t_min) {
+// *tie_only receives the margin without term (a): the bar for a kernel whose hit/miss decision is made in f64 (the
+// fp32 scan only nominates, conservatively), which leaves only (b) and (c) as legitimate fp32 bands.
+static double decision_margin(const Scene<double>& sc, const Ray<double>& ray, double t_min, double* tie_only) {
     const double kDisc = 16.0 / 16777216.0, kTmin = 0.05, kTie = 1e-3;
     const double a = ray.dir.norm_squared(), len = std::sqrt(a);
     const double inf = std::numeric_limits<double>::infinity();
@@ -126,18 +129,19 @@ static double decision_margin(const Scene<double>& sc, const Ray<double>& ray, d
             }
         }
     }
-    double m = inf;
+    double m = inf, mt = inf;
     for (const Q& s : q) {
         const double tc = -s.hb / a, ext = 1.5 * s.r / len;  // closest approach +- a generous sphere extent
         if (tc + ext < t_min || tc - ext > best) continue;   // cannot produce a hit in [t_min, best]
         m = std::min(m, std::fabs(s.disc / a) / std::max(s.oc2, s.r * s.r) / kDisc);
         if (s.disc >= 0) {
             double root = std::sqrt(s.disc);
-            for (double t : {(-s.hb - root) / a, (-s.hb + root) / a}) m = std::min(m, std::fabs(t / t_min - 1.0) / kTmin);
+            for (double t : {(-s.hb - root) / a, (-s.hb + root) / a}) mt = std::min(mt, std::fabs(t / t_min - 1.0) / kTmin);
         }
     }
-    if (std::isfinite(second)) m = std::min(m, (second - best) * len / std::max(best * len, best_r) / kTie);
-    return m;
+    if (std::isfinite(second)) mt = std::min(mt, (second - best) * len / std::max(best * len, best_r) / kTie);
+    if (tie_only) *tie_only = mt;
+    return std::min(m, mt);
 }
 
 template <class T>
@@ -155,7 +159,7 @@ static void intersect_impl(const rt_scene* flat, const rt_ray* rays, uint32_t n,
         std::memset(&o, 0, sizeof(o));
         Ray<double> rd{{rays[i].origin[0], rays[i].origin[1], rays[i].origin[2]},
                        {rays[i].dir[0], rays[i].dir[1], rays[i].dir[2]}, rays[i].time};
-        o.margin = decision_margin(scd, rd, t_min);
+        o.margin = decision_margin(scd, rd, t_min, &o.margin_tie);
         if (!got) continue;
         o.hit = 1;
         o.sphere_id = h.sphere_id;

@@ -235,10 +235,12 @@ __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b,
 // Root extraction for one ray of one sphere whose line test passed somewhere in the wave.  Strict <: the
 // first sphere in list order keeps a tie (hit.rs:100-110 narrows t_max with a half-open range; the lists are
 // stably sorted, so coincident spheres keep their world order).
-__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, uint32_t& best, int& idx) {
+// `lo`: candidates whose key is <= lo were nominated before and rejected by the f64 test (see hit_end): skipped.
+// lo = -1 skips nothing (keys of valid roots are bit patterns of non-negative floats: non-negative as ints).
+__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, int lo, uint32_t& best, int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
     const uint32_t key = __float_as_uint(b - __builtin_copysignf(s, q));
-    const bool closer = key < best;
+    const bool closer = key < best && (int)key > lo;
     best = closer ? key : best;
     idx = closer ? slot : idx;
 }
@@ -252,8 +254,8 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 // The root-extraction side of a group: second level, per sphere, again wave-uniform (about one sphere in four
 // of a group that got here is met by some lane).
 __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (&q)[kGroup], const f2 (&disc)[kGroup],
-                                               int slot0, uint32_t& best_a, uint32_t& best_b, int& idx_a, int& idx_b,
-                                               unsigned* dbg) {
+                                               int slot0, int lo_a, int lo_b, uint32_t& best_a, uint32_t& best_b,
+                                               int& idx_a, int& idx_b, unsigned* dbg) {
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) {
         const int hit = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
@@ -263,8 +265,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (
             RT_STAT(4, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0))) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))));
             RT_STAT(5, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0)) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))) != 0);
             RT_STAT(6, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0) && __float_as_uint(b[k].x - 1.0f) < best_a) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0) && __float_as_uint(b[k].y - 1.0f) < best_b)) != 0);
-            take_root(b[k].x, q[k].x, disc[k].x, slot0 + k, best_a, idx_a);
-            take_root(b[k].y, q[k].y, disc[k].y, slot0 + k, best_b, idx_b);
+            take_root(b[k].x, q[k].x, disc[k].x, slot0 + k, lo_a, best_a, idx_a);
+            take_root(b[k].y, q[k].y, disc[k].y, slot0 + k, lo_b, best_b, idx_b);
         }
     }
 }
@@ -279,8 +281,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (
 // (disc >= 0 <=> sign bit clear; one v_max3_i32 per sphere folds the 2*kGroup sign bits, one compare and one
 // wave-uniform branch per group decide).  Upload orders the lists along a Morton curve so the spheres of a group
 // are neighbours and the groups a wave's rays meet are few.
-__device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, uint32_t& best_a, uint32_t& best_b,
-                                             int& idx_a, int& idx_b) {
+__device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, int lo_a, int lo_b, uint32_t& best_a,
+                                             uint32_t& best_b, int& idx_a, int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
 #ifdef RT_NOSCAN
@@ -301,7 +303,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                 any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));  // one v_max3_i32
             }
             RT_STAT(0, 1);
-            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, base, best_a, best_b, idx_a, idx_b, dbg); }
+            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, base, lo_a, lo_b, best_a, best_b, idx_a, idx_b, dbg); }
         };
 #if RT_ASM_PREFETCH
         static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
@@ -356,7 +358,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
         }
         RT_STAT(0, 1);
-        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, S.ns_pad + base, best_a, best_b, idx_a, idx_b, dbg); }
+        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, S.ns_pad + base, lo_a, lo_b, best_a, best_b, idx_a, idx_b, dbg); }
     }
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
@@ -404,6 +406,13 @@ struct HitWork {
     int id_best;
     float inv_len;
 };
+// The scan is CONSERVATIVE and the f64 test decides: the scan direction is the unit direction times (1 + 8 ulp),
+// which inflates b^2 by 16 ulp -- more than the worst-case rounding of disc = b^2 - (|oc|^2 - r^2), ~15 ulp of
+// |oc|^2 (three roundings in b squared, three in q, one in disc, the normalisation of d), and b^2 ~ |oc|^2 for
+// every sphere the line passes near.  So a sphere the exact line meets always has disc >= 0 in fp32, whatever
+// |oc| / r is (a radius-0.1 sphere 300 away is hit or missed at random by a plain fp32 discriminant); the price is
+// a band of false nominations, which the f64 test of the nominee rejects (HitRec::kRetry below).
+constexpr float kScanInflate = 1.0f + 8.0f / 16777216.0f;
 __device__ __forceinline__ double dir_len2(const Ray& r) {
     return (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
 }
@@ -421,22 +430,30 @@ __device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, f
         }
     }
     const float len2 = (float)a;
-    w.inv_len = fast_rsq(len2);
+    w.inv_len = fast_rsq(len2) * kScanInflate;
     if (w.id_best < 0) return kInfBits;
-    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * w.inv_len));
+    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * w.inv_len));  // same (inflated) units as the keys
     return __float_as_uint(fmaxf(tb, 0.0f));
 }
+// HitRec::sphere == kRetry: the scan's nominee (key = bits of HitRec::t) was a false positive of the conservative
+// fp32 test.  The ray is traced AGAIN with that key as the floor `lo` of the scan: candidates at or below it are
+// skipped, so the next-closest candidate gets its f64 test, until one is accepted or none is left.  (Keeping only
+// the nominee and falling back to the sky on a rejection would lose the real hit behind a grazed sphere.)
+constexpr int kRetry = -2;
 __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float t_min, HitWork& w, uint32_t best,
                                           int slot) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    HitRec h;
     if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
         const int id = S.scan_id[slot];
         double t;
-        if (id >= 0 && sphere_hit_f64(S, id, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t) && t < w.t_best) {
-            w.t_best = t; w.id_best = id;
+        if (id >= 0 && sphere_hit_f64(S, id, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t)) {
+            if (t < w.t_best) { w.t_best = t; w.id_best = id; }  // else a big sphere is closer: it keeps the hit
+        } else {
+            h.sphere = kRetry; h.front = 0; h.t = __uint_as_float(best); h.p = {0, 0, 0}; h.n = {0, 0, 0};
+            return h;
         }
     }
-    HitRec h;
     h.sphere = w.id_best;
     if (w.id_best < 0) {
         h.front = 0; h.t = 0.0f; h.p = {0, 0, 0}; h.n = {0, 0, 0};
@@ -461,6 +478,8 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     h.n = {(float)nx, (float)ny, (float)nz};
     return h;
 }
+// the scan floor of a ray whose previous trace ended in kRetry (else -1: nothing to skip)
+__device__ __forceinline__ int retry_floor(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
 
 // HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
 // three steps so that a caller can re-read its scene arguments between them (render_kernel):
@@ -500,12 +519,20 @@ __device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, co
     if (do_a) ha = hit_end(S, ra, t_min, x.wa, x.best_a, x.slot_a);
     if (do_b) hb = hit_end(S, rb, t_min, x.wb, x.best_b, x.slot_b);
 }
+// one-shot form for the batch kernel: retraces on the spot while any lane of the wave holds a rejected nominee
 __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                              float t_min, HitRec& ha, HitRec& hb) {
-    Hit2 x;
-    closest_begin(S, ra, rb, do_a, do_b, t_min, x);
-    scan_spheres(S.lists, x.p, x.best_a, x.best_b, x.slot_a, x.slot_b);
-    closest_end(S, ra, rb, do_a, do_b, t_min, x, ha, hb);
+    ha.sphere = hb.sphere = -1;
+    int lo_a = -1, lo_b = -1;
+    while (__ballot(do_a || do_b) != 0ull) {  // wave-uniform: every lane runs the packed scan together
+        Hit2 x;
+        HitRec na, nb;
+        closest_begin(S, ra, rb, do_a, do_b, t_min, x);
+        scan_spheres(S.lists, x.p, lo_a, lo_b, x.best_a, x.best_b, x.slot_a, x.slot_b);
+        closest_end(S, ra, rb, do_a, do_b, t_min, x, na, nb);
+        if (do_a) { ha = na; lo_a = retry_floor(na); do_a = na.sphere == kRetry; }
+        if (do_b) { hb = nb; lo_b = retry_floor(nb); do_b = nb.sphere == kRetry; }
+    }
 }
 
 // ------------------------------------------------------------------ textures

@@ -12,6 +12,7 @@
 #include <numeric>
 #include <cstdio>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -31,8 +32,14 @@ constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
 // 1/8 of the) samples of a launch, which are cut into kUnitSppB-sample units so that the waves finish together.
 constexpr uint32_t kUnitSppA = 48, kUnitSppB = 8, kTailSpan = 128;
 constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes are computed in 32 bits)
-constexpr float kBigRadius = 50.0f;  // spheres at/above this radius (or |c| >= 500) take the f64 test
-constexpr float kBigCenter = 500.0f;
+// Spheres that take the per-ray f64 test instead of the fp32 scan: those whose radius exceeds kBigRatio times the
+// (lower) median radius of the scene, the kMaxBig largest of them at most.  The scan orders candidates by fp32
+// keys whose absolute error grows with |oc| (~16 ulp of |oc|): a sphere that dwarfs the others (the r = 1000 ground
+// under r = 0.2 balls) has |oc| ~ r for every ray near its surface, and its key error (~1e-3 there) would
+// misorder it against the small spheres resting on it.  The rule is a RATIO, so a scene scaled by any factor is
+// classified the same way (round 1 used r >= 50 or |c| >= 500 in absolute units).
+constexpr float kBigRatio = 32.0f;
+constexpr size_t kMaxBig = 64;
 
 // Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
 // radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
@@ -161,6 +168,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
+            // a slot whose nominee the f64 test rejected in the previous pass (h[s].sphere == kRetry) keeps its ray
+            // and is traced again below with that nominee's key as the scan floor: no scatter, no new random numbers
+            const bool retry = P.alive && h[s].sphere == kRetry;
             const unsigned long long need = __ballot(!P.alive);
             bool fresh = false;
             uint32_t x = 0, y = 0;
@@ -180,7 +190,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 }
             }
             next = min(next + (uint32_t)__popcll(need), total);
-            if (fresh || P.alive) {
+            if (fresh || (P.alive && !retry)) {
                 const ArgsPtr K = launder(K0);  // camera + image geometry: read here, not held across the pass
                 uint32_t r[4];
                 philox4x32_10(K->k0, K->k1, P.pix, P.smp, fresh ? (uint32_t)DIM_PIXEL : DIM_BOUNCE0 + P.depth, 0u, r);
@@ -220,13 +230,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
         {
             Hit2 x;
+            const int lo[2] = {ps[0].alive ? retry_floor(h[0]) : -1, ps[1].alive ? retry_floor(h[1]) : -1};
             closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
                 L.stat = K->S.lists.stat; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
-                scan_spheres(L, x.p, x.best_a, x.best_b, x.slot_a, x.slot_b);
+                scan_spheres(L, x.p, lo[0], lo[1], x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
             closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
         }
@@ -236,7 +247,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
-            if (P.alive) {
+            if (P.alive && h[s].sphere != kRetry) {  // (a rejected nominee: same ray segment again next pass)
                 ++n_rays;
                 if (h[s].sphere < 0) {
                     P.alive = false;
@@ -621,11 +632,30 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         if (s->material_id[i] >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "sphere material_id out of range");
         const float r = s->radius[i];
         if (!(r > 0.0f) || !std::isfinite(r)) return fail(c, RT_ERR_BAD_ARG, "sphere radius must be finite and > 0");
+        const float coords[6] = {s->c0x[i], s->c0y[i], s->c0z[i], s->dcx[i], s->dcy[i], s->dcz[i]};
+        for (float v : coords)
+            if (!std::isfinite(v)) return fail(c, RT_ERR_BAD_ARG, "sphere centre / motion must be finite");
         inv_rad[i] = (float)(1.0 / (double)r);
+    }
+    std::vector<char> is_big(s->n_spheres, 0);
+    if (s->n_spheres > 1) {
+        std::vector<float> sorted_r(s->radius, s->radius + s->n_spheres);
+        std::nth_element(sorted_r.begin(), sorted_r.begin() + (s->n_spheres - 1) / 2, sorted_r.end());
+        const float limit = kBigRatio * sorted_r[(s->n_spheres - 1) / 2];
+        std::vector<uint32_t> cand;
+        for (uint32_t i = 0; i < s->n_spheres; ++i)
+            if (s->radius[i] > limit) cand.push_back(i);
+        if (cand.size() > kMaxBig) {  // keep the largest; the rest ride the scan with coarser tie ordering
+            std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return s->radius[x] > s->radius[y]; });
+            cand.resize(kMaxBig);
+        }
+        for (uint32_t i : cand) is_big[i] = 1;
+    }
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const float r = s->radius[i];
         const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
-        const float cm = std::fmax(std::fmax(std::fabs(s->c0x[i]), std::fabs(s->c0y[i])), std::fabs(s->c0z[i]));
-        if (r >= kBigRadius || cm >= kBigCenter) {
-            big_id.push_back((int32_t)i);
+        if (is_big[i]) {
+            big_id.push_back((int32_t)i);  // world order (first wins an exact tie, hit.rs:100-110)
         } else if (moving) {
             mov_a.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], -(r * r)));
             mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
@@ -686,9 +716,11 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             mov_a.swap(a2); mov_b.swap(b2); mov_id.swap(i2);
         }
     }
-    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, 1.0f)); stat_id.push_back(-1); }
+    // pads are never nominated: -r^2 = +inf makes disc = b^2 - inf negative whatever the ray is
+    const float kPad = std::numeric_limits<float>::infinity();
+    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, kPad)); stat_id.push_back(-1); }
     while (mov_a.size() % kChunk) {
-        mov_a.push_back(make_float4(0, 0, 0, 1.0f));
+        mov_a.push_back(make_float4(0, 0, 0, kPad));
         mov_b.push_back(make_float4(0, 0, 0, 0));
         mov_id.push_back(-1);
     }

@@ -32,10 +32,13 @@ def rel_err(a, b, floor=1e-30):
     return np.abs(a - b) / np.maximum(np.abs(b), floor)
 
 
-def check_hits(got, exp, eps_margin, tol=1e-5, max_excluded=0.12):
+def check_hits(got, exp, eps_margin, tol=1e-5, max_excluded=0.12, margin="margin_tie"):
     """north_star check (1): hit/miss, sphere id, material id and front_face BIT-EXACT for every ray whose
-    f64 decision margin exceeds eps_margin; t and normal within `tol` relative. Returns stats dict."""
-    ok = exp["margin"] >= eps_margin
+    f64 decision margin exceeds eps_margin; t and normal within `tol` relative. Returns stats dict.
+    margin = "margin_tie" (default): only rays with a root on the t_min boundary or a near-tie between two spheres
+    are exempt -- hit/miss itself is decided in f64 on the device, so there is no discriminant band.
+    margin = "margin": round 1's bar, which also exempted 16 fp32 ulps around a grazing discriminant."""
+    ok = exp[margin] >= eps_margin
     n = len(exp)
     stats = {"n": n, "excluded": int((~ok).sum())}
     assert stats["excluded"] <= max_excluded * n, f"too many rays excluded by the margin: {stats}"

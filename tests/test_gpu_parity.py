@@ -16,10 +16,12 @@ from helpers import check_hits, rel_err, scene_checksum
 
 pytestmark = pytest.mark.gpu
 
-# Rays whose decision margin (oracle_capi.cpp::decision_margin, in units of "16 fp32 ulps of the cancelled
-# discriminant / 5 % of t_min / 1e-3 relative near-tie") is below 1 are excluded from the bit-exact checks: any
-# fp32 sphere quadratic cancels b^2 against |oc|^2, so inside that band fp32 and f64 may disagree on hit/miss;
-# outside it they must not. Excluded counts are printed per case (0.1-0.2 % of generic rays).
+# Rays whose TIE margin (oracle_capi.cpp::decision_margin without its discriminant term: "5 % of t_min for a root
+# on the range boundary / 1e-3 relative near-tie between two spheres") is below 1 are excluded from the bit-exact
+# checks: the device ORDERS candidates by fp32 keys.  Hit/miss itself has no exempt band since round 2: the fp32 scan
+# is conservative and the nominee is decided in f64, with a retrace when it is rejected (rt_device.h, kRetry), so a
+# grazing ray must agree with the oracle bit for bit.  Excluded counts are printed per case (~0.01 % of generic rays;
+# round 1's bar, which exempted 16 fp32 ulps around a grazing discriminant, excluded 0.1-5 %).
 EPS_MARGIN = 1.0
 TOL = 1e-5         # north_star: t, normal, scatter direction within 1e-5 relative
 
@@ -54,7 +56,7 @@ def test_intersect_batches(ctx, api, name, case):
     ctx.upload(w.scene)
     got = ctx.intersect_batch(g[f"{case}_rays"], 1e-3)
     # the grazing set aims within r*(1 +- 4e-3..3e-2) of a limb on purpose: part of it lands inside the band
-    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL, max_excluded=0.10 if case == "grazing" else 0.01)
+    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL, max_excluded=0.005)
     print(name, case, stats)
     miss = got["hit"] == 0
     assert not got["t"][miss].any() and not got["normal"][miss].any()  # a miss is all zeros
@@ -78,7 +80,7 @@ def test_intersect_large_incoherent_batch(ctx, api, orc, name):
     rays = np.concatenate([cam, rnd])
     got = ctx.intersect_batch(rays)
     exp = orc.intersect_batch(w.scene, rays)
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.01)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.001)
     print(name, st, "hits", int(exp["hit"].sum()))
     assert exp["hit"].sum() > 0.5 * len(rays)
 
@@ -365,6 +367,94 @@ def test_caller_built_scenes_up_to_the_limit(ctx, api, orc, n, moving_every):
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
     assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+
+
+def _scaled_world(api, name, k, aspect):
+    """The factory scene `name` with every length multiplied by k (centres, motion, radii, camera, lens), as a
+    caller-built scene.  Directions, colours and texture frequencies-per-length (freq / k) follow."""
+    w = api.World(name, seed=1, aspect=aspect)
+    a, s = w.arrays(), w.scene
+    mats = [(s.materials[i].type, tuple(s.materials[i].albedo), s.materials[i].fuzz, s.materials[i].ior,
+             s.materials[i].texture_id) for i in range(s.n_materials)]
+    texs = []
+    for i in range(s.n_textures):
+        t = api.Texture.from_buffer_copy(s.textures[i])
+        t.freq = t.freq / k
+        texs.append(t)
+    fs = api.FlatScene(a["c0"].astype(np.float64) * k, a["radius"].astype(np.float64) * k, a["material_id"], mats, texs,
+                       dc=a["dc"].astype(np.float64) * k)
+    cam = api.Camera.from_buffer_copy(w.camera)
+    for f in ("origin", "lower_left", "horiz", "vert"):
+        v = getattr(cam, f)
+        for j in range(3):
+            v[j] = v[j] * k
+    cam.lens_radius = cam.lens_radius * k
+    return w, fs, cam
+
+
+@pytest.mark.parametrize("name", ["FinalStatic", "Random"])
+@pytest.mark.parametrize("k", [0.01, 100.0])
+def test_scaled_scenes(ctx, api, orc, name, k):
+    """Nothing in the library is in absolute units: the final scenes scaled x0.01 and x100 (camera and t_min with
+    them) pass the same ray-batch bar against the oracle on the scaled scene, and render the same image as the
+    unscaled scene.  (Round 1 sent spheres with r >= 50 or |c| >= 500 to the f64 list: x100 put every sphere
+    there, x0.01 left the cancelling ground in the fp32 scan.)"""
+    w, fs, cam = _scaled_world(api, name, k, 240 / 160)
+    ctx.upload(fs.scene)
+    rng = np.random.default_rng(11)
+    n = 32768
+    rays = ctx.camera_rays(cam, rng.random((n, 2), dtype=np.float32), rng.random((n, 4), dtype=np.float32))
+    rnd = np.zeros(n, api.ray_dtype)
+    rnd["origin"] = np.stack([rng.uniform(-12, 12, n), rng.uniform(0.0, 3.0, n), rng.uniform(-12, 12, n)], 1) * k
+    d = rng.normal(size=(n, 3))
+    rnd["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
+    rnd["time"] = rng.random(n)
+    rays = np.concatenate([rays, rnd])
+    got = ctx.intersect_batch(rays, 1e-3 * k)
+    exp = orc.intersect_batch(fs.scene, rays, 1e-3 * k)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.001)
+    print(name, k, st, "hits", int(exp["hit"].sum()))
+    assert exp["hit"].sum() > 0.5 * len(rays)
+    # same counter streams, same geometry up to scale: the image is the unscaled scene's image
+    p = api.make_params(240, 160, 64, seed=w.render_seed, t_min=1e-3 * k)
+    img, st1 = ctx.render(cam, p)
+    ctx.upload(w.scene)
+    ref, st0 = ctx.render(w.camera, api.make_params(240, 160, 64, seed=w.render_seed))
+    r = rmse_gamma(img, ref)
+    print(name, k, "rmse(gamma) scaled vs unscaled", r, "rays", st1.rays_traced, st0.rays_traced)
+    assert r < 0.01 and abs(int(st1.rays_traced) - int(st0.rays_traced)) < 3e-3 * st0.rays_traced
+
+
+def test_small_spheres_far_from_the_rays(ctx, api, orc):
+    """|oc| / r in the thousands: radius-0.1 spheres seen from 300-600 away.  A plain fp32 discriminant b^2 - (|oc|^2
+    - r^2) has an ulp of |oc|^2 (0.008 at 300) against r^2 = 0.01, i.e. hits or misses such spheres at random; the
+    conservative scan nominates every sphere the line may meet and the f64 test decides, so hit/miss and ids are
+    bit-exact against the oracle here too, WITHOUT any discriminant band (margin_tie only)."""
+    rng = np.random.default_rng(5)
+    n_s = 400
+    c0 = np.empty((n_s, 3), np.float32)
+    c0[:, 0] = rng.uniform(-3, 3, n_s); c0[:, 1] = rng.uniform(-3, 3, n_s); c0[:, 2] = rng.uniform(-3, 3, n_s)
+    rad = np.full(n_s, 0.1, np.float32)
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0)]
+    fs = api.FlatScene(c0, rad, np.zeros(n_s, np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))])
+    ctx.upload(fs.scene)
+    n = 65536
+    rays = np.zeros(n, api.ray_dtype)
+    dist = rng.uniform(300, 600, n)
+    o = rng.normal(size=(n, 3))
+    o = o / np.linalg.norm(o, axis=1, keepdims=True) * dist[:, None]
+    # aim at (or just past the limb of) a random sphere: half the rays hit, a quarter graze within 2 % of r
+    tgt = c0[rng.integers(0, n_s, n)].astype(np.float64)
+    perp = np.cross(tgt - o, rng.normal(size=(n, 3)))
+    perp /= np.linalg.norm(perp, axis=1, keepdims=True)
+    off = np.where(rng.random(n) < 0.5, rng.uniform(0, 1.5, n), rng.uniform(0.98, 1.02, n)) * 0.1
+    rays["origin"] = o
+    rays["dir"] = (tgt + perp * off[:, None] - o) * rng.uniform(0.5, 2.0, (n, 1)) / dist[:, None]
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(fs.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.02)  # near-ties: 400 spheres in a 6-unit box seen from afar
+    print(st, "hits", int(exp["hit"].sum()), "excluded by round 1's discriminant band:", int((exp["margin"] < 1).sum()))
+    assert 0.3 * n < exp["hit"].sum() < 0.95 * n
 
 
 def test_max_depth_semantics(ctx, api, orc):
