@@ -63,11 +63,16 @@ constexpr int kMaxFused = 6;  // 6 x 9 KiB + the per-wave accumulators stay unde
 
 // Device view of an uploaded scene.
 // fp32 scan lists (read with scalar loads: wave-uniform index)
+// All centres are relative to `origin` (the middle of the small spheres' bounding box, chosen on upload): the
+// expanded form of the static test cancels |c|^2 + |o|^2 against 2 c.o, so coordinates are kept small.
 struct ScanLists {
-    const float4* stat;   // ns_pad x {cx, cy, cz, -r^2}; pads have -r^2 = +1 at c = 0 (never hit)
-    const float4* mov_a;  // nm_pad x {c0x, c0y, c0z, -r^2}
-    const float4* mov_b;  // nm_pad x {dcx, dcy, dcz, 0}
+    const float4* stat;     // ns_pad x {cx, cy, cz, |c|^2 - r^2}; pads have w = +inf (never nominated)
+    const float* stat_nr2;  // ns_pad x -r^2 (read only by the root-extraction side)
+    const float4* mov_a;    // nm_pad x {c0x, c0y, c0z, -r^2}; pads -r^2 = +inf
+    const float4* mov_b;    // nm_pad x {dcx, dcy, dcz, 0}
     int32_t ns_pad, nm_pad;
+    float ox, oy, oz;       // origin of the scan frame (world coordinates)
+    float cmax;             // max |c| over the static list, in the scan frame
 };
 struct DevScene {
     ScanLists lists;
@@ -209,26 +214,50 @@ __device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef float f2 __attribute__((ext_vector_type(2)));
 typedef const __attribute__((address_space(4))) v4f* cv4p;  // constant address space => scalar loads
+__device__ __forceinline__ f2 splat2(float v) { return f2{v, v}; }
 __device__ __forceinline__ cv4p as_scalar(const float4* p) { return (cv4p)(uintptr_t)p; }
 __device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
 
 // the two rays of a lane, in the scan frame (component-wise pairs {A, B})
 struct Pair {
-    f2 ox, oy, oz;  // o' = o + t_min*d
-    f2 dx, dy, dz;  // unit direction
+    f2 m2ox, m2oy, m2oz;  // -2 o', o' = o + t_min*d - origin (the direct forms recover o' = -0.5 * m2o exactly)
+    f2 dx, dy, dz;        // unit direction (x kScanInflate)
     f2 time;
+    // per-ray terms of the expanded static test
+    f2 nod;               // -(o' . d^)
+    f2 qb;                // |o'|^2 - E, E = kExpandErr (|o'| + cmax)^2: the error bound of the expanded disc
 };
 
-// b and q of one sphere for both rays.  static sphere s = {cx, cy, cz, -r^2}
-__device__ __forceinline__ void terms_static(v4f s, const Pair& r, f2& b, f2& q) {
-    const f2 ocx = s.x - r.ox, ocy = s.y - r.oy, ocz = s.z - r.oz;
+// STATIC spheres, every sphere: the EXPANDED form, 8 packed ops for both rays (the direct form below needs 10):
+//   b = c.d^ - o'.d^          3 fma   (sphere components are SGPR broadcasts; nod = -(o'.d^) per ray)
+//   q = (|c|^2 - r^2) + |o'|^2 - 2 c.o'    1 add + 3 fma   (w = |c|^2 - r^2 per sphere in f64 on upload)
+//   disc = b^2 - q            1 fma
+// It cancels numbers of size (|c| + |o'|)^2 =: M^2, so it is used ONLY as a conservative pre-filter: its rounding
+// error is below 26 ulp of M^2 (3 roundings in b, squared: 8 |b| M; w, |o'|^2, their sum and three fma in q: 6 M^2;
+// b^2 and disc: 2 M^2; the rounding of c and o' into the scan frame: 4 M^2; the normalisation of d^: 5 M^2), and
+// E = 32 ulp of M^2 is subtracted from q through the per-ray term qb, so a sphere the exact line meets always has
+// disc >= 0 here.  A sphere that passes is tested again in the DIRECT form (terms_static_direct) on the
+// root-extraction side, which is as exact as fp32 gets (error ~ulp of |oc|^2, covered by kScanInflate) and
+// yields the key; the pre-filter's false positives (a band of ~E / 2r around the limb: 1-2 % of r for the
+// final scene seen from its camera) die there as disc < 0 without ever being nominated.
+constexpr float kExpandErr = 32.0f / 16777216.0f;
+__device__ __forceinline__ f2 disc_static_expanded(v4f s, const Pair& r) {
+    const f2 b = fma2(f2{s.z, s.z}, r.dz, fma2(f2{s.y, s.y}, r.dy, fma2(f2{s.x, s.x}, r.dx, r.nod)));
+    const f2 q = fma2(f2{s.z, s.z}, r.m2oz, fma2(f2{s.y, s.y}, r.m2oy, fma2(f2{s.x, s.x}, r.m2ox, s.w + r.qb)));
+    return fma2(b, b, -q);
+}
+// b and q of one sphere for both rays, DIRECT form.  static sphere: centre s.xyz, nr2 = -r^2
+__device__ __forceinline__ void terms_static_direct(v4f s, float nr2, const Pair& r, f2& b, f2& q) {
+    const f2 h = splat2(0.5f);
+    const f2 ocx = fma2(r.m2ox, h, splat2(s.x)), ocy = fma2(r.m2oy, h, splat2(s.y)), ocz = fma2(r.m2oz, h, splat2(s.z));  // c - o'
     b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
-    q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{s.w, s.w})));
+    q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{nr2, nr2})));
 }
 // moving sphere a = {c0, -r^2}, m = {dc, 0}: center(time) = c0 + time*dc (shape.rs:96-98)
 __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b, f2& q) {
-    const f2 ocx = fma2(r.time, f2{m.x, m.x}, a.x - r.ox), ocy = fma2(r.time, f2{m.y, m.y}, a.y - r.oy),
-             ocz = fma2(r.time, f2{m.z, m.z}, a.z - r.oz);
+    const f2 h = splat2(0.5f);
+    const f2 ocx = fma2(r.time, f2{m.x, m.x}, fma2(r.m2ox, h, splat2(a.x))), ocy = fma2(r.time, f2{m.y, m.y}, fma2(r.m2oy, h, splat2(a.y))),
+             ocz = fma2(r.time, f2{m.z, m.z}, fma2(r.m2oz, h, splat2(a.z)));
     b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
     q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
 }
@@ -244,15 +273,23 @@ __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b,
 struct Floor {
     int lo_a, lo_b, ls_a, ls_b;
 };
+// The root: "near root if it is in range, else the far root" (shape.rs:53-61) with the range start folded into
+// o': as unsigned bit patterns a negative float loses to any non-negative one, so the root taken is
+// umin(bits(b - s), bits(b + s)), and v_min3_u32 with the best so far gives the new best in one instruction.
 template <bool kFloor>
-__device__ __forceinline__ void take_root(float b, float q, float disc, int slot, int lo, int ls, uint32_t& best,
-                                          int& idx) {
+__device__ __forceinline__ void take_root(float b, float disc, int slot, int lo, int ls, uint32_t& best, int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
-    const uint32_t key = __float_as_uint(b - __builtin_copysignf(s, q));
-    bool closer = key < best;
-    if (kFloor) closer = closer && (int)key > lo - (slot > ls ? 1 : 0);
-    best = closer ? key : best;
-    idx = closer ? slot : idx;
+    const uint32_t k1 = __float_as_uint(b - s), k2 = __float_as_uint(b + s);
+    if (kFloor) {
+        const uint32_t key = min(k1, k2);
+        const bool closer = key < best && (int)key > lo - (slot > ls ? 1 : 0);
+        best = closer ? key : best;
+        idx = closer ? slot : idx;
+    } else {
+        const uint32_t nb = min(min(k1, k2), best);  // v_min3_u32
+        idx = nb != best ? slot : idx;               // strictly closer
+        best = nb;
+    }
 }
 
 #ifdef RT_STATS
@@ -262,22 +299,23 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 #define RT_STAT(i, n)
 #endif
 // The root-extraction side of a group: second level, per sphere, again wave-uniform (about one sphere in four
-// of a group that got here is met by some lane).
-template <bool kFloor>
-__device__ __forceinline__ void roots_of_group(const f2 (&b)[kGroup], const f2 (&q)[kGroup], const f2 (&disc)[kGroup],
-                                               int slot0, const Floor& fl, uint32_t& best_a, uint32_t& best_b,
-                                               int& idx_a, int& idx_b, unsigned* dbg) {
+// of a group that got here is met by some lane).  `filter` holds the discriminants that sent the wave here (the
+// expanded pre-filter for the static list, the direct ones for the moving list); `direct(k, b, disc)` yields the
+// direct-form b and disc of sphere k for both rays.
+template <bool kFloor, class Direct>
+__device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direct&& direct, int slot0, const Floor& fl,
+                                               uint32_t& best_a, uint32_t& best_b, int& idx_a, int& idx_b,
+                                               unsigned* dbg) {
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) {
-        const int hit = max(__float_as_int(disc[k].x), __float_as_int(disc[k].y));
+        const int hit = max(__float_as_int(filter[k].x), __float_as_int(filter[k].y));
         if (RT_TAILCOND2) {
+            f2 b, disc;
+            direct(k, b, disc);
             RT_STAT(2, 1);
-            RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0)));
-            RT_STAT(4, __popcll(__builtin_amdgcn_ballot_w64(disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0))) + __popcll(__builtin_amdgcn_ballot_w64(disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))));
-            RT_STAT(5, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0)) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0))) != 0);
-            RT_STAT(6, __builtin_amdgcn_ballot_w64((disc[k].x >= 0 && (b[k].x > 0 || q[k].x < 0) && __float_as_uint(b[k].x - 1.0f) < best_a) || (disc[k].y >= 0 && (b[k].y > 0 || q[k].y < 0) && __float_as_uint(b[k].y - 1.0f) < best_b)) != 0);
-            take_root<kFloor>(b[k].x, q[k].x, disc[k].x, slot0 + k, fl.lo_a, fl.ls_a, best_a, idx_a);
-            take_root<kFloor>(b[k].y, q[k].y, disc[k].y, slot0 + k, fl.lo_b, fl.ls_b, best_b, idx_b);
+            RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc.x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc.y >= 0)));
+            take_root<kFloor>(b.x, disc.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, idx_a);
+            take_root<kFloor>(b.y, disc.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, idx_b);
         }
     }
 }
@@ -306,16 +344,23 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
         // in flight (SMEM returns out of order, so the wait is always lgkmcnt(0): the load must be a whole
         // group ahead to hide its latency with only four waves per SIMD).  ns_pad is a multiple of 2 * kGroup.
         auto group = [&](const v4f (&sp)[kGroup], int base) {
-            f2 b[kGroup], q[kGroup], disc[kGroup];
+            f2 disc[kGroup];
             int any = (int)0x80000000;
 #pragma unroll
             for (int k = 0; k < kGroup; ++k) {
-                terms_static(sp[k], r, b[k], q[k]);
-                disc[k] = fma2(b[k], b[k], -q[k]);
+                disc[k] = disc_static_expanded(sp[k], r);
                 any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));  // one v_max3_i32
             }
             RT_STAT(0, 1);
-            if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group<kFloor>(b, q, disc, base, fl, best_a, best_b, idx_a, idx_b, dbg); }
+            if (RT_TAILCOND) {
+                RT_STAT(1, 1);
+                const v4f nr2 = *(cv4p)(uintptr_t)(S.stat_nr2 + base);  // -r^2 of the group: one scalar load, this side only
+                roots_of_group<kFloor>(disc, [&](int k, f2& b, f2& d) {
+                    f2 q;
+                    terms_static_direct(sp[k], nr2[k], r, b, q);
+                    d = fma2(b, b, -q);
+                }, base, fl, best_a, best_b, idx_a, idx_b, dbg);
+            }
         };
 #if RT_ASM_PREFETCH
         static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
@@ -370,7 +415,11 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
         }
         RT_STAT(0, 1);
-        if (RT_TAILCOND) { RT_STAT(1, 1); roots_of_group<kFloor>(b, q, disc, S.ns_pad + base, fl, best_a, best_b, idx_a, idx_b, dbg); }
+        if (RT_TAILCOND) {
+            RT_STAT(1, 1);
+            roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + base, fl, best_a,
+                                   best_b, idx_a, idx_b, dbg);
+        }
     }
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
@@ -521,14 +570,23 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     p.dx = f2{ra.d.x * x.wa.inv_len, rb.d.x * x.wb.inv_len};
     p.dy = f2{ra.d.y * x.wa.inv_len, rb.d.y * x.wb.inv_len};
     p.dz = f2{ra.d.z * x.wa.inv_len, rb.d.z * x.wb.inv_len};
-    p.ox = f2{fmaf(t_min, ra.d.x, ra.o.x), fmaf(t_min, rb.d.x, rb.o.x)};
-    p.oy = f2{fmaf(t_min, ra.d.y, ra.o.y), fmaf(t_min, rb.d.y, rb.o.y)};
-    p.oz = f2{fmaf(t_min, ra.d.z, ra.o.z), fmaf(t_min, rb.d.z, rb.o.z)};
+    // o' = o + t_min*d - origin in f64, rounded once: its error is an ulp of the SCAN-FRAME coordinate
+    const ScanLists& L = S.lists;
+    auto frame = [&](float o, float d, float org) { return (float)(((double)o + (double)t_min * (double)d) - (double)org); };
+    f2 ox = f2{frame(ra.o.x, ra.d.x, L.ox), frame(rb.o.x, rb.d.x, L.ox)};
+    f2 oy = f2{frame(ra.o.y, ra.d.y, L.oy), frame(rb.o.y, rb.d.y, L.oy)};
+    f2 oz = f2{frame(ra.o.z, ra.d.z, L.oz), frame(rb.o.z, rb.d.z, L.oz)};
     p.time = f2{ra.time, rb.time};
     // a dead ray rides through the packed scan: park it (d = 0, far origin => disc = -|oc|^2 - ... < 0 for every
-    // sphere) so it never sends its wave into a root-extraction group
-    if (!do_a) { p.dx.x = p.dy.x = p.dz.x = 0.0f; p.ox.x = 1e18f; p.oy.x = p.oz.x = 0.0f; p.time.x = 0.0f; }
-    if (!do_b) { p.dx.y = p.dy.y = p.dz.y = 0.0f; p.ox.y = 1e18f; p.oy.y = p.oz.y = 0.0f; p.time.y = 0.0f; }
+    // sphere, in either form) so it never sends its wave into a root-extraction group
+    if (!do_a) { p.dx.x = p.dy.x = p.dz.x = 0.0f; ox.x = 1e18f; oy.x = oz.x = 0.0f; p.time.x = 0.0f; }
+    if (!do_b) { p.dx.y = p.dy.y = p.dz.y = 0.0f; ox.y = 1e18f; oy.y = oz.y = 0.0f; p.time.y = 0.0f; }
+    // the per-ray terms of the expanded static test
+    p.m2ox = ox * -2.0f; p.m2oy = oy * -2.0f; p.m2oz = oz * -2.0f;
+    p.nod = -fma2(oz, p.dz, fma2(oy, p.dy, ox * p.dx));
+    const f2 oo = fma2(oz, oz, fma2(oy, oy, ox * ox));
+    const f2 m = f2{fast_sqrt(oo.x), fast_sqrt(oo.y)} + L.cmax;
+    p.qb = fma2(m * m, splat2(-kExpandErr), oo);
     x.slot_a = x.slot_b = -1;
 }
 __device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,

@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
@@ -652,18 +652,40 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         }
         for (uint32_t i : cand) is_big[i] = 1;
     }
+    // The scan frame: centres relative to the middle of the small spheres' bounding box (motion included), so that
+    // the expanded static test (rt_device.h) cancels numbers no larger than the scene itself.
+    double lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
+    bool any_small = false;
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
-        const float r = s->radius[i];
+        if (is_big[i]) continue;
+        const double c0[3] = {s->c0x[i], s->c0y[i], s->c0z[i]}, dc[3] = {s->dcx[i], s->dcy[i], s->dcz[i]};
+        for (int a = 0; a < 3; ++a) {
+            const double v0 = c0[a], v1 = c0[a] + dc[a];
+            if (!any_small) { lo3[a] = std::min(v0, v1); hi3[a] = std::max(v0, v1); }
+            else { lo3[a] = std::min(lo3[a], std::min(v0, v1)); hi3[a] = std::max(hi3[a], std::max(v0, v1)); }
+        }
+        any_small = true;
+    }
+    const float org[3] = {(float)(0.5 * (lo3[0] + hi3[0])), (float)(0.5 * (lo3[1] + hi3[1])), (float)(0.5 * (lo3[2] + hi3[2]))};
+    std::vector<float> stat_nr2;
+    double cmax = 0.0;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const double r = s->radius[i];
         const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
+        const double cx = (double)s->c0x[i] - org[0], cy = (double)s->c0y[i] - org[1], cz = (double)s->c0z[i] - org[2];
         if (is_big[i]) {
             big_id.push_back((int32_t)i);  // world order (first wins an exact tie, hit.rs:100-110)
         } else if (moving) {
-            mov_a.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], -(r * r)));
+            mov_a.push_back(make_float4((float)cx, (float)cy, (float)cz, (float)-(r * r)));
             mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
             mov_id.push_back((int32_t)i);
         } else {
-            stat.push_back(make_float4(s->c0x[i], s->c0y[i], s->c0z[i], -(r * r)));
+            // w = |c|^2 - r^2 from the ROUNDED centre the kernel multiplies with, in f64, rounded once
+            const double fx = (float)cx, fy = (float)cy, fz = (float)cz;
+            stat.push_back(make_float4((float)cx, (float)cy, (float)cz, (float)(fx * fx + fy * fy + fz * fz - r * r)));
+            stat_nr2.push_back((float)-(r * r));
             stat_id.push_back((int32_t)i);
+            cmax = std::max(cmax, std::sqrt(fx * fx + fy * fy + fz * fz));
         }
     }
     // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
@@ -705,9 +727,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         {
             const std::vector<uint32_t> perm = morton_order(stat);
             std::vector<float4> s2(stat.size());
+            std::vector<float> r2(stat.size());
             std::vector<int32_t> i2(stat.size());
-            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = stat[perm[k]]; i2[k] = stat_id[perm[k]]; }
-            stat.swap(s2); stat_id.swap(i2);
+            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = stat[perm[k]]; r2[k] = stat_nr2[perm[k]]; i2[k] = stat_id[perm[k]]; }
+            stat.swap(s2); stat_nr2.swap(r2); stat_id.swap(i2);
         }
         {
             const std::vector<uint32_t> perm = morton_order(mov_a);  // by the centre at time 0
@@ -719,7 +742,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     }
     // pads are never nominated: -r^2 = +inf makes disc = b^2 - inf negative whatever the ray is
     const float kPad = std::numeric_limits<float>::infinity();
-    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, kPad)); stat_id.push_back(-1); }
+    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, kPad)); stat_nr2.push_back(kPad); stat_id.push_back(-1); }
     while (mov_a.size() % kChunk) {
         mov_a.push_back(make_float4(0, 0, 0, kPad));
         mov_b.push_back(make_float4(0, 0, 0, 0));
@@ -735,6 +758,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     int rc;
 #define UP(expr) if ((rc = (expr)) != RT_OK) { free_scene(c); return rc; }
     UP(dev_copy(c, stat.data(), stat.size(), &D.lists.stat));
+    UP(dev_copy(c, stat_nr2.data(), stat_nr2.size(), &D.lists.stat_nr2));
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
@@ -752,6 +776,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
     UP(dev_copy(c, fused.data(), fused.size(), &D.fused));
 #undef UP
+    D.lists.ox = org[0]; D.lists.oy = org[1]; D.lists.oz = org[2];
+    D.lists.cmax = (float)(cmax * (1.0 + 1e-6));
     D.lists.ns_pad = (int32_t)stat.size();
     D.lists.nm_pad = (int32_t)mov_a.size();
     D.n_big = (int32_t)big_id.size();
