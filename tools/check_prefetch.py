@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build-time check of the hand-pinned scalar prefetch in scan_spheres (rt_device.h).
 
-The next sphere group is fetched with an inline-asm `s_load_dwordx16 ... ; PF_LOAD` whose completion the
+The next sphere group is fetched with inline-asm `s_load_dwordx16 / s_load_dwordx4 ... ; PF_LOAD` whose completion the
 compiler does not track; the matching `s_waitcnt lgkmcnt(0) ; PF_WAIT` is the first point where the destination
 SGPRs may be touched.  This script reads the kernel ISA (the Makefile emits rt_lib.s), builds the control-flow
 graph of every function (labels, s_branch / s_cbranch_* targets, fall-through) and walks it forward from each
@@ -58,11 +58,11 @@ def check(path):
         return [i + 1] if i + 1 < len(ins) else []
 
     for i, (no, code, full) in enumerate(ins):
-        if "PF_LOAD" not in full or not code.startswith("s_load_dwordx16"):
+        if "PF_LOAD" not in full or not code.startswith("s_load_dword"):
             continue
         n_loads += 1
-        m = re.search(r"s_load_dwordx16\s+s\[(\d+):(\d+)\]", code)
-        dst = set(range(int(m.group(1)), int(m.group(2)) + 1))
+        m = re.search(r"s_load_dword(?:x\d+)?\s+(?:s\[(\d+):(\d+)\]|s(\d+))", code)  # x16 sphere group, x4 -r^2 group
+        dst = set(range(int(m.group(1)), int(m.group(2)) + 1)) if m.group(1) else {int(m.group(3))}
         seen, stack = set(), [j for j in successors(i)]
         while stack:
             j = stack.pop()
