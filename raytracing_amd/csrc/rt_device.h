@@ -21,7 +21,7 @@
 
 namespace rtd {
 
-constexpr int kChunk = 8;           // scan lists are padded to a multiple of this
+constexpr int kChunk = 16;          // scan lists are padded to a multiple of this (4 groups: one s_load_dwordx16 of bounds)
 #ifndef RT_GROUP
 #define RT_GROUP 4
 #endif
@@ -68,6 +68,7 @@ constexpr int kMaxFused = 6;  // 6 x 9 KiB + the per-wave accumulators stay unde
 struct ScanLists {
     const float4* stat;     // ns_pad x {cx, cy, cz, |c|^2 - r^2}; pads have w = +inf (never nominated)
     const float* stat_nr2;  // ns_pad x -r^2 (read only by the root-extraction side)
+    const float4* stat_bound;  // ns_pad / kGroup x {bx, by, bz, |b|^2 - R^2}: a sphere around each group of kGroup (w = +inf: all pads)
     const float4* mov_a;    // nm_pad x {c0x, c0y, c0z, -r^2}; pads -r^2 = +inf
     const float4* mov_b;    // nm_pad x {dcx, dcy, dcz, 0}
     int32_t ns_pad, nm_pad;
@@ -352,6 +353,31 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                 any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));  // one v_max3_i32
             }
             RT_STAT(0, 1);
+#ifdef RT_STATS
+            {  // would a bounding sphere of the group (and of the 8 / 16 spheres starting at an aligned base) be met by any lane?
+                auto met = [&](int n, const v4f* g) {
+                    float cx = 0, cy = 0, cz = 0;
+                    for (int k = 0; k < n; ++k) { cx += g[k].x / n; cy += g[k].y / n; cz += g[k].z / n; }
+                    float R = 0;
+                    for (int k = 0; k < n; ++k) {
+                        const float dx = g[k].x - cx, dy = g[k].y - cy, dz = g[k].z - cz;
+                        const float rr = sqrtf(fmaxf(0.f, g[k].x * g[k].x + g[k].y * g[k].y + g[k].z * g[k].z - g[k].w));
+                        if (g[k].w < 1e30f) R = fmaxf(R, sqrtf(dx * dx + dy * dy + dz * dz) + rr);
+                    }
+                    bool any_lane = false;
+                    for (int h = 0; h < 2; ++h) {
+                        const float ox = -0.5f * r.m2ox[h] , oy = -0.5f * r.m2oy[h], oz = -0.5f * r.m2oz[h];
+                        const float ex = cx - ox, ey = cy - oy, ez = cz - oz;
+                        const float bb = ex * r.dx[h] + ey * r.dy[h] + ez * r.dz[h];
+                        const float pp = ex * ex + ey * ey + ez * ez - bb * bb;
+                        const bool inside = ex * ex + ey * ey + ez * ez < R * R;
+                        any_lane |= (pp <= R * R && (bb > 0 || inside)) && (r.dx[h] != 0.f || r.dy[h] != 0.f || r.dz[h] != 0.f);
+                    }
+                    return __builtin_amdgcn_ballot_w64(any_lane) != 0;
+                };
+                RT_STAT(4, met(4, sp));
+            }
+#endif
             if (RT_TAILCOND) {
                 RT_STAT(1, 1);
                 const v4f nr2 = *(cv4p)(uintptr_t)(S.stat_nr2 + base);  // -r^2 of the group: one scalar load, this side only
@@ -362,47 +388,31 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                 }, base, fl, best_a, best_b, idx_a, idx_b, dbg);
             }
         };
-#if RT_ASM_PREFETCH
-        static_assert(kGroup == 4, "the asm prefetch moves one s_load_dwordx16 = 4 spheres");
-        typedef float v16f __attribute__((ext_vector_type(16)));
-        auto unpack = [](const v16f& v, v4f (&sp)[kGroup]) {
+        // GROUP CULLING.  Upload stores a bounding sphere around each group of kGroup list neighbours (Morton order
+        // makes them spatial neighbours); it goes through the same expanded test, and the members are fetched and
+        // tested only when some lane's line meets it: measured on configs[1], 34 % of the groups (a wave's 128 rays
+        // leave from a few hit points in all directions, so only distant groups are skipped).  One s_load_dwordx16
+        // brings the bounds of four groups.
+        static_assert(kGroup == 4 && kChunk == 16, "one s_load_dwordx16 = the bounds of 4 groups = one chunk");
+        const cv4p bd = as_scalar(S.stat_bound);
+        for (int base = 0; base < S.ns_pad; base += kChunk) {
+            v4f bound[kChunk / kGroup];
 #pragma unroll
-            for (int k = 0; k < kGroup; ++k) sp[k] = v4f{v[4 * k], v[4 * k + 1], v[4 * k + 2], v[4 * k + 3]};
-        };
-        v16f va, vb;
-        const cv4p p0 = st;
-        asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(va) : "s"(p0));
-        for (int base = 0; base < S.ns_pad; base += 2 * kGroup) {
-            asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(va));
-            const cv4p pb = st + base + kGroup;
-            asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(vb) : "s"(pb));
-            __builtin_amdgcn_sched_barrier(0);
-            v4f ga[kGroup];
-            unpack(va, ga);
-            group(ga, base);
-            asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(vb));
-            const cv4p pa = st + min(base + 2 * kGroup, S.ns_pad - kGroup);
-            asm volatile("s_load_dwordx16 %0, %1, 0x0 ; PF_LOAD" : "=&s"(va) : "s"(pa));
-            __builtin_amdgcn_sched_barrier(0);
-            v4f gb[kGroup];
-            unpack(vb, gb);
-            group(gb, base + kGroup);
+            for (int g = 0; g < kChunk / kGroup; ++g) bound[g] = bd[base / kGroup + g];
+#pragma unroll
+            for (int g = 0; g < kChunk / kGroup; ++g) {
+                const f2 d = disc_static_expanded(bound[g], r);
+                const int met = max(__float_as_int(d.x), __float_as_int(d.y));
+                RT_STAT(5, 1);
+                if (__builtin_amdgcn_ballot_w64(met >= 0) != 0) {
+                    RT_STAT(6, 1);
+                    v4f sp[kGroup];
+#pragma unroll
+                    for (int k = 0; k < kGroup; ++k) sp[k] = st[base + g * kGroup + k];
+                    group(sp, base + g * kGroup);
+                }
+            }
         }
-        asm volatile("s_waitcnt lgkmcnt(0) ; PF_WAIT" : "+s"(va));
-#else
-        v4f ga[kGroup], gb[kGroup];
-#pragma unroll
-        for (int k = 0; k < kGroup; ++k) ga[k] = st[k];
-        for (int base = 0; base < S.ns_pad; base += 2 * kGroup) {
-#pragma unroll
-            for (int k = 0; k < kGroup; ++k) gb[k] = st[base + kGroup + k];
-            group(ga, base);
-            const int nb = min(base + 2 * kGroup, S.ns_pad - kGroup);
-#pragma unroll
-            for (int k = 0; k < kGroup; ++k) ga[k] = st[nb + k];
-            group(gb, base + kGroup);
-        }
-#endif
     }
     const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
     for (int base = 0; base < S.nm_pad; base += kGroup) {

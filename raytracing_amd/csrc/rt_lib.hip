@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
@@ -748,6 +748,26 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         mov_b.push_back(make_float4(0, 0, 0, 0));
         mov_id.push_back(-1);
     }
+    // bounding sphere of each group of kGroup static spheres (scan frame, from the rounded centres): centre = the
+    // mean of the members, radius = the farthest member surface, widened by 1e-5 relative for the f64 -> fp32 steps
+    std::vector<float4> stat_bound(stat.size() / kGroup);
+    for (size_t g = 0; g < stat_bound.size(); ++g) {
+        double cx = 0, cy = 0, cz = 0;
+        int n = 0;
+        for (int k = 0; k < kGroup; ++k)
+            if (stat_id[g * kGroup + k] >= 0) { cx += stat[g * kGroup + k].x; cy += stat[g * kGroup + k].y; cz += stat[g * kGroup + k].z; ++n; }
+        if (n == 0) { stat_bound[g] = make_float4(0, 0, 0, kPad); continue; }
+        const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
+        double R = 0;
+        for (int k = 0; k < kGroup; ++k) {
+            const size_t i = g * kGroup + k;
+            if (stat_id[i] < 0) continue;
+            const double dx = (double)stat[i].x - bx, dy = (double)stat[i].y - by, dz = (double)stat[i].z - bz;
+            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(-(double)stat_nr2[i]));
+        }
+        R *= 1.0 + 1e-5;
+        stat_bound[g] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
+    }
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
     const size_t lds_need = lds_scene_bytes((int)fused.size());
@@ -759,6 +779,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
 #define UP(expr) if ((rc = (expr)) != RT_OK) { free_scene(c); return rc; }
     UP(dev_copy(c, stat.data(), stat.size(), &D.lists.stat));
     UP(dev_copy(c, stat_nr2.data(), stat_nr2.size(), &D.lists.stat_nr2));
+    UP(dev_copy(c, stat_bound.data(), stat_bound.size(), &D.lists.stat_bound));
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));

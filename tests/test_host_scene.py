@@ -201,7 +201,7 @@ def test_library_exports_every_declared_symbol(api):
 def test_struct_layouts_match_the_header(api, tmp_path):
     """ctypes mirrors == what a C compiler lays out for include/rtx_hip.h."""
     names = ["rt_noise_table", "rt_texture", "rt_material", "rt_scene", "rt_camera", "rt_params", "rt_stats",
-             "rt_ray", "rt_hit", "rt_scatter"]
+             "rt_ray", "rt_hit", "rt_scatter", "rt_multi_stats"]
     src = '#include <stdio.h>\n#include "rtx_hip.h"\nint main(void){' + "".join(
         f'printf("%zu\\n", sizeof({n}));' for n in names) + 'printf("%zu %zu\\n", __builtin_offsetof(rt_params, seed), __builtin_offsetof(rt_params, t_min)); return 0;}'
     c = tmp_path / "sz.c"
@@ -213,7 +213,8 @@ def test_struct_layouts_match_the_header(api, tmp_path):
     for m, sz in zip(mirrors, out[:7]):
         assert C.sizeof(m) == int(sz), m
     assert [api.ray_dtype.itemsize, api.hit_dtype.itemsize, api.scatter_dtype.itemsize] == [int(x) for x in out[7:10]]
-    assert (api.Params.seed.offset, api.Params.t_min.offset) == (int(out[10]), int(out[11]))
+    assert C.sizeof(api.MultiStats) == int(out[10])
+    assert (api.Params.seed.offset, api.Params.t_min.offset) == (int(out[11]), int(out[12]))
 
 
 def test_no_device_is_a_loud_error(api):

@@ -19,3 +19,4 @@ for scene in sys.argv[1:] or ["FinalStatic"]:
           "per taken group %.2f" % (stk / max(gt, 1)), "useful ray-roots per taken sphere (of 128) %.2f" % (r_useful / max(stk, 1)),
           "in-front %.2f" % (r_front / max(stk, 1)), "spheres w/ in-front hit / sphere %.3f" % (s_front / (4 * g)),
           "and within bound+1 %.3f" % (s_front_bound / (4 * g)))
+    print(scene, "static groups whose bounding sphere some lane's ray meets: %.3f" % (r_front / g))
