@@ -73,8 +73,8 @@ def check(path):
                 continue
             seen.add(j)
             jno, jcode, jfull = ins[j]
-            if "PF_WAIT" in jfull:
-                continue  # this path is safe from here on
+            if "PF_WAIT" in jfull or (jcode.startswith("s_waitcnt") and "lgkmcnt(0)" in jcode):
+                continue  # this path is safe from here on (ANY full lgkm wait means the data has arrived)
             if jcode.split()[0] == "s_endpgm":
                 bad.append((no, jno, "program ends before PF_WAIT"))
                 continue
