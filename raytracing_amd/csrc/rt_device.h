@@ -71,6 +71,7 @@ struct ScanLists {
     const float4* stat_bound;  // ns_pad / kGroup x {bx, by, bz, |b|^2 - R^2}: a sphere around each group of kGroup (w = +inf: all pads)
     const float4* mov_a;    // nm_pad x {c0x, c0y, c0z, -r^2}; pads -r^2 = +inf
     const float4* mov_b;    // nm_pad x {dcx, dcy, dcz, 0}
+    const float4* mov_bound;  // nm_pad / kGroup x bound of the group over the whole motion for time in [0, 1]
     int32_t ns_pad, nm_pad;
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
     float cmax;             // max |c| over the static list, in the scan frame
@@ -427,8 +428,18 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             }
         }
     }
-    const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
+    // The moving list, culled the same way: a group's bound covers its members' whole motion for time in [0, 1]
+    // (the segments c0 .. c0 + dc).  A ray outside that time range (the fixed-batch entry point takes any) switches
+    // the culling off for its wave.
+    const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b), mbd = as_scalar(S.mov_bound);
+    const bool cull_moving = S.nm_pad > 0 && __builtin_amdgcn_ballot_w64(!(r.time.x >= 0.0f && r.time.x <= 1.0f) ||
+                                                                        !(r.time.y >= 0.0f && r.time.y <= 1.0f)) == 0ull;
     for (int base = 0; base < S.nm_pad; base += kGroup) {
+        if (cull_moving) {
+            RT_STAT(5, 1);
+            if (__builtin_amdgcn_ballot_w64(bound_reject_bits(mbd[base / kGroup], r) >= 0) == 0ull) continue;
+            RT_STAT(6, 1);
+        }
         f2 b[kGroup], q[kGroup], disc[kGroup];
         int any = (int)0x80000000;
 #pragma unroll

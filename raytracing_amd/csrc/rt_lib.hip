@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
@@ -768,6 +768,36 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         R *= 1.0 + 1e-5;
         stat_bound[g] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
     }
+    // the same for the moving list: the bound covers both ends of every member's segment c0 .. c0 + dc (a sphere
+    // is convex, so it covers the whole segment), i.e. every ray time in [0, 1]
+    std::vector<float4> mov_bound(mov_a.size() / kGroup);
+    for (size_t g = 0; g < mov_bound.size(); ++g) {
+        double cx = 0, cy = 0, cz = 0;
+        int n = 0;
+        for (int k = 0; k < kGroup; ++k) {
+            const size_t i = g * kGroup + k;
+            if (mov_id[i] < 0) continue;
+            cx += mov_a[i].x + 0.5 * mov_b[i].x; cy += mov_a[i].y + 0.5 * mov_b[i].y; cz += mov_a[i].z + 0.5 * mov_b[i].z;
+            ++n;
+        }
+        if (n == 0) { mov_bound[g] = make_float4(0, 0, 0, kPad); continue; }
+        const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
+        double R = 0;
+        for (int k = 0; k < kGroup; ++k) {
+            const size_t i = g * kGroup + k;
+            if (mov_id[i] < 0) continue;
+            const double rad = std::sqrt(-(double)mov_a[i].w);
+            for (int e = 0; e < 2; ++e) {
+                // the end point as the kernel computes it at time 0 / 1 (fp32 c0 + dc), widened below for its rounding
+                const double dx = (double)mov_a[i].x + e * (double)mov_b[i].x - bx, dy = (double)mov_a[i].y + e * (double)mov_b[i].y - by,
+                             dz = (double)mov_a[i].z + e * (double)mov_b[i].z - bz;
+                R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + rad);
+            }
+        }
+        R *= 1.0 + 1e-5;
+        mov_bound[g] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
+        cmax = std::max(cmax, std::sqrt((double)bx * bx + (double)by * by + (double)bz * bz));
+    }
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
     const size_t lds_need = lds_scene_bytes((int)fused.size());
@@ -780,6 +810,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, stat.data(), stat.size(), &D.lists.stat));
     UP(dev_copy(c, stat_nr2.data(), stat_nr2.size(), &D.lists.stat_nr2));
     UP(dev_copy(c, stat_bound.data(), stat_bound.size(), &D.lists.stat_bound));
+    UP(dev_copy(c, mov_bound.data(), mov_bound.size(), &D.lists.mov_bound));
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
