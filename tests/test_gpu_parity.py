@@ -85,6 +85,29 @@ def test_intersect_large_incoherent_batch(ctx, api, orc, name):
     assert exp["hit"].sum() > 0.5 * len(rays)
 
 
+def test_moving_spheres_at_any_ray_time(ctx, api, orc):
+    """center(time) = c0 + time * dc is defined for every time (shape.rs:96-98); the device culls groups of moving
+    spheres with bounds built for time in [0, 1] and must switch that off for rays outside it."""
+    w = api.World("Random", seed=1, aspect=1200 / 800)
+    ctx.upload(w.scene)
+    rng = np.random.default_rng(99)
+    n = 32768
+    rays = np.zeros(n, api.ray_dtype)
+    rays["origin"] = np.stack([rng.uniform(-12, 12, n), rng.uniform(0.0, 4.0, n), rng.uniform(-12, 12, n)], 1)
+    d = rng.normal(size=(n, 3))
+    rays["dir"] = d / np.linalg.norm(d, axis=1, keepdims=True) * rng.uniform(0.5, 2.0, (n, 1))
+    rays["time"] = rng.uniform(-1.0, 3.0, n)            # mixed: most waves hold a ray outside [0, 1]
+    rays["time"][: n // 4] = rng.random(n // 4)         # ... and the first waves hold none
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(w.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.005)  # at time 3 the spheres have risen into one another: more near-ties
+    moving = np.abs(w.arrays()["dc"]).sum(1) > 0
+    hit_moving = exp["hit"].astype(bool) & moving[np.clip(exp["sphere_id"], 0, None)]
+    print(st, "hits on moving spheres", int(hit_moving.sum()), "of them at time outside [0,1]",
+          int((hit_moving & ((rays["time"] < 0) | (rays["time"] > 1))).sum()))
+    assert hit_moving.sum() > 1000 and (hit_moving & ((rays["time"] < 0) | (rays["time"] > 1))).sum() > 500
+
+
 def test_intersect_edge_cases(ctx, api, orc):
     w = api.World("Balls", seed=1)
     ctx.upload(w.scene)
