@@ -236,7 +236,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; L.stat_levels = K->S.lists.stat_levels; L.mov_levels = K->S.lists.mov_levels; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
@@ -748,56 +748,64 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         mov_b.push_back(make_float4(0, 0, 0, 0));
         mov_id.push_back(-1);
     }
-    // bounding sphere of each group of kGroup static spheres (scan frame, from the rounded centres): centre = the
-    // mean of the members, radius = the farthest member surface, widened by 1e-5 relative for the f64 -> fp32 steps
-    std::vector<float4> stat_bound(stat.size() / kGroup);
-    for (size_t g = 0; g < stat_bound.size(); ++g) {
-        double cx = 0, cy = 0, cz = 0;
-        int n = 0;
-        for (int k = 0; k < kGroup; ++k)
-            if (stat_id[g * kGroup + k] >= 0) { cx += stat[g * kGroup + k].x; cy += stat[g * kGroup + k].y; cz += stat[g * kGroup + k].z; ++n; }
-        if (n == 0) { stat_bound[g] = make_float4(0, 0, 0, kPad); continue; }
-        const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
-        double R = 0;
-        for (int k = 0; k < kGroup; ++k) {
-            const size_t i = g * kGroup + k;
-            if (stat_id[i] < 0) continue;
-            const double dx = (double)stat[i].x - bx, dy = (double)stat[i].y - by, dz = (double)stat[i].z - bz;
-            R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + std::sqrt(-(double)stat_nr2[i]));
-        }
-        R *= 1.0 + 1e-5;
-        stat_bound[g] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
-    }
-    // the same for the moving list: the bound covers both ends of every member's segment c0 .. c0 + dc (a sphere
-    // is convex, so it covers the whole segment), i.e. every ray time in [0, 1]
-    std::vector<float4> mov_bound(mov_a.size() / kGroup);
-    for (size_t g = 0; g < mov_bound.size(); ++g) {
-        double cx = 0, cy = 0, cz = 0;
-        int n = 0;
-        for (int k = 0; k < kGroup; ++k) {
-            const size_t i = g * kGroup + k;
-            if (mov_id[i] < 0) continue;
-            cx += mov_a[i].x + 0.5 * mov_b[i].x; cy += mov_a[i].y + 0.5 * mov_b[i].y; cz += mov_a[i].z + 0.5 * mov_b[i].z;
-            ++n;
-        }
-        if (n == 0) { mov_bound[g] = make_float4(0, 0, 0, kPad); continue; }
-        const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
-        double R = 0;
-        for (int k = 0; k < kGroup; ++k) {
-            const size_t i = g * kGroup + k;
-            if (mov_id[i] < 0) continue;
-            const double rad = std::sqrt(-(double)mov_a[i].w);
-            for (int e = 0; e < 2; ++e) {
-                // the end point as the kernel computes it at time 0 / 1 (fp32 c0 + dc), widened below for its rounding
-                const double dx = (double)mov_a[i].x + e * (double)mov_b[i].x - bx, dy = (double)mov_a[i].y + e * (double)mov_b[i].y - by,
-                             dz = (double)mov_a[i].z + e * (double)mov_b[i].z - bz;
-                R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + rad);
+    // Bounding spheres for the hierarchical culling (rt_device.h, walk): for every node of every level the sphere
+    // around the member SPHERES it covers (not around child bounds: tighter), in the scan frame, from the rounded
+    // centres the kernel uses; for a moving sphere both ends of its segment c0 .. c0 + dc (a sphere is convex, so the
+    // whole motion for time in [0, 1] is inside).  Centre = the mean of the members' mid-points, radius = the
+    // farthest member surface, widened by 1e-5 relative for the f64 -> fp32 steps.
+    // Which upper levels are worth their tests: a wave's 128 rays leave from a few hit points in all directions, so
+    // a node of radius R at distance D is met by some ray with probability ~ min(1, 16 R^2 / D^2); testing it (12
+    // instructions) instead of its four children (48) pays below ~0.75, i.e. for R < 0.15 X with D ~ 0.7 X and X the
+    // half-diagonal of the small spheres' bounding box.  Measured: the 16-sphere level (R ~ 2.9 of X = 16) LOSES
+    // 12 % on configs[1], all levels together gain 40 % at 16384 spheres.  A ratio, like every threshold here.
+    const double extent = 0.5 * std::sqrt((hi3[0] - lo3[0]) * (hi3[0] - lo3[0]) + (hi3[1] - lo3[1]) * (hi3[1] - lo3[1]) +
+                                          (hi3[2] - lo3[2]) * (hi3[2] - lo3[2]));
+    auto build_bounds = [&](const std::vector<float4>& a, const std::vector<float4>* dcv, const std::vector<float>* nr2v,
+                            const std::vector<int32_t>& ids, int32_t* levels) {
+        *levels = 0;
+        const int n_chunks = (int)(a.size() / kChunk);
+        std::vector<float4> out((size_t)bound_level_offset(n_chunks, kLevels), make_float4(0, 0, 0, kPad));
+        for (int L = 0; L < kLevels; ++L) {
+            const size_t span = L == 0 ? (size_t)kGroup : (size_t)kChunk << (2 * (L - 1));  // spheres per node
+            const int off = bound_level_offset(n_chunks, L), cnt = bound_level_count(n_chunks, L);
+            double r_sum = 0;
+            int r_n = 0;
+            for (int j = 0; j < cnt; ++j) {
+                const size_t lo = (size_t)j * span, hi = std::min(a.size(), lo + span);
+                double cx = 0, cy = 0, cz = 0;
+                int n = 0;
+                for (size_t i = lo; i < hi; ++i) {
+                    if (ids[i] < 0) continue;
+                    const double h = dcv ? 0.5 : 0.0;
+                    cx += a[i].x + (dcv ? h * (*dcv)[i].x : 0.0); cy += a[i].y + (dcv ? h * (*dcv)[i].y : 0.0);
+                    cz += a[i].z + (dcv ? h * (*dcv)[i].z : 0.0);
+                    ++n;
+                }
+                if (n == 0) continue;  // only pads: w = +inf, never met
+                const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
+                double R = 0;
+                for (size_t i = lo; i < hi; ++i) {
+                    if (ids[i] < 0) continue;
+                    const double rad = std::sqrt(-(double)(nr2v ? (*nr2v)[i] : a[i].w));
+                    for (int e = 0; e < (dcv ? 2 : 1); ++e) {
+                        const double dx = (double)a[i].x + (dcv ? e * (double)(*dcv)[i].x : 0.0) - bx,
+                                     dy = (double)a[i].y + (dcv ? e * (double)(*dcv)[i].y : 0.0) - by,
+                                     dz = (double)a[i].z + (dcv ? e * (double)(*dcv)[i].z : 0.0) - bz;
+                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + rad);
+                    }
+                }
+                R *= 1.0 + 1e-5;
+                r_sum += R; ++r_n;
+                out[(size_t)off + j] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
+                cmax = std::max(cmax, std::sqrt((double)bx * bx + (double)by * by + (double)bz * bz));
             }
+            if (L >= 1 && r_n >= 2 && r_sum / r_n < 0.15 * extent) *levels |= 1 << L;
         }
-        R *= 1.0 + 1e-5;
-        mov_bound[g] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
-        cmax = std::max(cmax, std::sqrt((double)bx * bx + (double)by * by + (double)bz * bz));
-    }
+        return out;
+    };
+    int32_t stat_levels = 0, mov_levels = 0;
+    const std::vector<float4> stat_bound = build_bounds(stat, nullptr, &stat_nr2, stat_id, &stat_levels);
+    const std::vector<float4> mov_bound = build_bounds(mov_a, &mov_b, nullptr, mov_id, &mov_levels);
     std::vector<int32_t> scan_id(stat_id);
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
     const size_t lds_need = lds_scene_bytes((int)fused.size());
@@ -830,6 +838,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
 #undef UP
     D.lists.ox = org[0]; D.lists.oy = org[1]; D.lists.oz = org[2];
     D.lists.cmax = (float)(cmax * (1.0 + 1e-6));
+    D.lists.stat_levels = stat_levels; D.lists.mov_levels = mov_levels;
     D.lists.ns_pad = (int32_t)stat.size();
     D.lists.nm_pad = (int32_t)mov_a.size();
     D.n_big = (int32_t)big_id.size();
