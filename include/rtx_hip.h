@@ -27,8 +27,9 @@ extern "C" {
 
 #define RT_ABI_VERSION 1
 
-/* Limits.  The sphere lists are streamed through the scalar cache (not LDS), so the sphere limit is a sanity bound
- * on a brute-force scan (cost per ray segment is linear in it), not a capacity: every reference scene has < 500.
+/* Limits.  The sphere lists are streamed through the scalar cache (not LDS), so the sphere limit is a sanity bound,
+ * not a capacity: every reference scene has < 500.  Cost per ray segment grows slower than the count (bounding
+ * spheres over runs of 4 .. 1024 list neighbours let a wave skip what none of its rays can meet).
  * Noise tables (2 KiB each) are staged in LDS.  Images: 2 <= width, height <= 65536 and at most 2^28 pixels; batch entry
  * points take at most 2^30 elements per call. */
 #define RT_MAX_SPHERES 16384
