@@ -27,6 +27,8 @@ static int usage(const char* argv0, const char* msg) {
                  "  -r, --rng <seed>             Use a specific seed for the rng.\n"
                  "  -o, --output <file.ppm>      Write the encoded image (extension; default render.ppm)\n"
                  "  -d, --device <ordinal>       HIP device (extension; default 0)\n"
+                 "  -g, --gpus <n>               render on devices 0..n-1, samples split across them, one RCCL\n"
+                 "                               reduce (extension; default: one device, no RCCL needed)\n"
                  "  <scene>                      The scene to render [default: Random]. Possible values:\n",
                  argv0);
     for (const char* const* n = rth_scene_names(); *n; ++n) std::fprintf(stderr, "      %s\n", *n);
@@ -43,7 +45,7 @@ static bool parse_u64(const char* s, uint64_t* out) {
 }
 
 int main(int argc, char** argv) {
-    uint64_t width = 1024, height = 576, samples = 100, max_depth = 100, seed = 0, device = 0;
+    uint64_t width = 1024, height = 576, samples = 100, max_depth = 100, seed = 0, device = 0, gpus = 0;
     int has_seed = 0, antialias = 1;
     std::string scene = "Random", output = "render.ppm";
     for (int i = 1; i < argc; ++i) {
@@ -55,6 +57,7 @@ int main(int argc, char** argv) {
         else if (a == "-m" || a == "--max-depth") { if (!val(&max_depth)) return usage(argv[0], "bad --max-depth"); }
         else if (a == "-r" || a == "--rng") { if (!val(&seed)) return usage(argv[0], "bad --rng"); has_seed = 1; }
         else if (a == "-d" || a == "--device") { if (!val(&device)) return usage(argv[0], "bad --device"); }
+        else if (a == "-g" || a == "--gpus") { if (!val(&gpus) || gpus == 0 || gpus > RT_MAX_DEVICES) return usage(argv[0], "bad --gpus"); }
         else if (a == "-n" || a == "--no-aa") antialias = 0;
         else if (a == "-o" || a == "--output") { if (i + 1 >= argc) return usage(argv[0], "bad --output"); output = argv[++i]; }
         else if (a == "--help") return usage(argv[0], nullptr);
@@ -66,17 +69,35 @@ int main(int argc, char** argv) {
     if (samples == 0 || samples > 65535) return usage(argv[0], "samples must be in 1..=65535 (NonZeroU16)");
     if (max_depth == 0 || max_depth > 0xFFFFFFFFull) return usage(argv[0], "max-depth must be a non-zero u32");
 
-    rth_world* world = nullptr;
-    if (rth_world_create(scene.c_str(), has_seed, seed, (double)width / (double)height, &world) != RT_OK) {
+    // everything below is released on every return path
+    struct Handles {
+        rth_world* world = nullptr;
+        rt_ctx* ctx = nullptr;
+        rt_multi* multi = nullptr;
+        ~Handles() { rt_multi_destroy(multi); rt_destroy(ctx); rth_world_destroy(world); }
+    } h;
+    if (rth_world_create(scene.c_str(), has_seed, seed, (double)width / (double)height, &h.world) != RT_OK) {
         std::fprintf(stderr, "%s\n", rth_last_error());  // parse_scene's message (config.rs:71-79)
         return 2;
     }
-    rt_ctx* ctx = nullptr;
-    if (rt_create((int)device, &ctx) != RT_OK) {
+    rth_world* world = h.world;
+    if (rt_create((int)device, &h.ctx) != RT_OK) {  // (also used for the encode step of a multi-device render)
         std::fprintf(stderr, "rt_create: %s\n", rt_last_error(nullptr));
         return 1;
     }
-    if (rt_upload_scene(ctx, rth_world_scene(world)) != RT_OK) {
+    rt_ctx* ctx = h.ctx;
+    if (gpus) {
+        std::vector<int> ord(gpus);
+        for (uint64_t i = 0; i < gpus; ++i) ord[i] = (int)i;
+        if (rt_multi_create(ord.data(), (int)gpus, &h.multi) != RT_OK) {
+            std::fprintf(stderr, "rt_multi_create: %s\n", rt_multi_last_error(nullptr));
+            return 1;
+        }
+        if (rt_multi_upload_scene(h.multi, rth_world_scene(world)) != RT_OK) {
+            std::fprintf(stderr, "rt_multi_upload_scene: %s\n", rt_multi_last_error(h.multi));
+            return 1;
+        }
+    } else if (rt_upload_scene(ctx, rth_world_scene(world)) != RT_OK) {
         std::fprintf(stderr, "rt_upload_scene: %s\n", rt_last_error(ctx));
         return 1;
     }
@@ -88,7 +109,15 @@ int main(int argc, char** argv) {
     std::vector<float> rgb((size_t)width * height * 3);
     rt_stats st{};
     const auto t0 = std::chrono::steady_clock::now();  // main.rs:62
-    if (rt_render(ctx, rth_world_camera(world), &p, rgb.data(), &st) != RT_OK) {
+    if (gpus) {
+        rt_multi_stats ms{};
+        if (rt_multi_render(h.multi, rth_world_camera(world), &p, rgb.data(), &ms) != RT_OK) {
+            std::fprintf(stderr, "rt_multi_render: %s\n", rt_multi_last_error(h.multi));
+            return 1;
+        }
+        st.samples = ms.samples; st.rays_traced = ms.rays_traced; st.kernel_ms = ms.kernel_ms;
+        std::fprintf(stderr, "%u device(s), RCCL reduce %.3f ms\n", ms.n_devices, ms.reduce_ms);
+    } else if (rt_render(ctx, rth_world_camera(world), &p, rgb.data(), &st) != RT_OK) {
         std::fprintf(stderr, "rt_render: %s\n", rt_last_error(ctx));
         return 1;
     }
@@ -120,7 +149,5 @@ int main(int argc, char** argv) {
         std::fwrite(row.data(), 1, row.size(), f);
     }
     std::fclose(f);
-    rt_destroy(ctx);
-    rth_world_destroy(world);
     return 0;
 }

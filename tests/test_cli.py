@@ -59,3 +59,19 @@ def test_cli_ppm_matches_binding(api, ctx, tmp_path):
     assert bad == 0
     ref = np.stack([(enc >> 16) & 255, (enc >> 8) & 255, enc & 255], -1).astype(np.uint8).reshape(64, 96, 3)
     assert np.array_equal(pix, ref)
+
+
+@pytest.mark.gpu
+def test_cli_gpus_flag_renders_through_rt_multi(tmp_path):
+    """--gpus n goes through rt_multi_* (RCCL communicator, spp split, reduce); with n = 1 the PPM is the one-device
+    PPM (the two means differ by one fp32 rounding at most: allow one grey level in a handful of pixels)."""
+    a, b = tmp_path / "a.ppm", tmp_path / "b.ppm"
+    args = ("-w", "96", "-h", "64", "-s", "8", "-m", "20", "-r", "5", "Balls")
+    r1 = run(*args, "-o", str(a))
+    r2 = run(*args, "-g", "1", "-o", str(b))
+    assert r1.returncode == 0 and r2.returncode == 0, r1.stderr + r2.stderr
+    assert "1 device(s), RCCL reduce" in r2.stderr
+    pa = np.frombuffer(a.read_bytes(), dtype=np.uint8).astype(int)
+    pb = np.frombuffer(b.read_bytes(), dtype=np.uint8).astype(int)
+    assert pa.shape == pb.shape and np.abs(pa - pb).max() <= 1 and (pa != pb).sum() <= 8
+    assert run(*args, "-g", "0").returncode == 2 and run(*args, "-g", "99").returncode == 2
