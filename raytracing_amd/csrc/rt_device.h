@@ -31,9 +31,6 @@ constexpr int kChunk = 16;          // scan lists are padded to a multiple of th
 #ifndef RT_TAILCOND
 #define RT_TAILCOND __builtin_expect(__builtin_amdgcn_ballot_w64(any >= 0) != 0, 0)
 #endif
-#ifndef RT_ASM_PREFETCH
-#define RT_ASM_PREFETCH 1
-#endif
 constexpr int kGroup = RT_GROUP;    // spheres per lazy-root group of the scan (divides kChunk)
 constexpr int kLevels = 5;          // bound levels: groups (4 spheres), then 16, 64, 256, 1024 spheres
 // number of nodes of bound level L for a list of n_chunks chunks, and the level's offset in the bound array

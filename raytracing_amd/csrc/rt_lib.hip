@@ -16,9 +16,6 @@
 #include <string>
 #include <vector>
 
-#ifndef RT_PREFETCH
-#define RT_PREFETCH 0
-#endif
 #include "rt_device.h"
 
 using namespace rtd;
