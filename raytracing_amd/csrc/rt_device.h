@@ -101,6 +101,7 @@ struct DevScene {
     int32_t n_fused;
     int32_t n_spheres;
     int32_t n_textures;
+    int32_t any_moving;  // some sphere has dc != 0 (else the f64 tests skip the dc gathers: c0 + time * 0 = c0 exactly)
 };
 
 // Kernel arguments are re-read from the KERNARG segment (constant address space => scalar loads) at chosen points
@@ -186,19 +187,22 @@ struct HitRec {
     f3 p, n;
 };
 
+// sin / cos of u TURNS (2 pi u), u in [0, 1): v_sin_f32 / v_cos_f32 take their argument in turns and are within
+// 1.3e-7 (absolute) of the exact value on that range (measured over all 2^24 multiples of 2^-24), the same as the
+// 43-instruction sincospif expansion they replace.
+__device__ __forceinline__ float turn_sin(float u) { return __builtin_amdgcn_sinf(u); }
+__device__ __forceinline__ float turn_cos(float u) { return __builtin_amdgcn_cosf(u); }
 // uniform on the unit sphere surface / in the unit disc from two uniforms (same maps as the
 // oracle; same distributions as rand_distr::UnitSphere / UnitDisc used at vec3.rs:53-62)
 __device__ __forceinline__ f3 map_unit_sphere(float u0, float u1) {
     const float z = 1.0f - 2.0f * u0;
     const float r = fast_sqrt(fmaxf(0.0f, 1.0f - z * z));
-    float s, c;
-    sincospif(2.0f * u1, &s, &c);
+    const float s = turn_sin(u1), c = turn_cos(u1);
     return {r * c, r * s, z};
 }
 __device__ __forceinline__ f3 map_unit_disk(float u0, float u1) {
     const float r = fast_sqrt(u0);
-    float s, c;
-    sincospif(2.0f * u1, &s, &c);
+    const float s = turn_sin(u1), c = turn_cos(u1);
     return {r * c, r * s, 0.0f};
 }
 
@@ -491,12 +495,40 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
 // near root if t_min <= t < t_max else far root.  The fp32 scan only NOMINATES a sphere; this f64 test DECIDES
 // it, so a grazing or far-origin false positive of the scan is rejected here (the ray then keeps its big-sphere
 // hit or misses).  `clamp_disc` clamps nothing but f64 rounding noise (|disc| < 1e-14 hb^2) to a tangent hit.
+// f64 reciprocal and square root without the library's scaling and special cases (12 and 22 VALU instructions as
+// compiled from 1.0 / a and sqrt(x)): the arguments here are |d|^2 of an fp32 direction and a discriminant of fp32
+// inputs, normal f64 numbers or exactly 0.  v_rcp_f64 / v_rsq_f64 seed two Newton steps (rcp: <= 1 ulp) or one
+// Goldschmidt step and one correction (sqrt: ~1e-16 relative; the result is narrowed to fp32 or compared with
+// another root, nothing depends on its last bit).
+__device__ __forceinline__ double rcp_f64(double a) {
+    double y = __builtin_amdgcn_rcp(a);
+    double e = __builtin_fma(-a, y, 1.0);
+    y = __builtin_fma(y, e, y);
+    e = __builtin_fma(-a, y, 1.0);
+    return __builtin_fma(y, e, y);
+}
+__device__ __forceinline__ double sqrt_f64(double x) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g);
+    h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    g = __builtin_fma(d, h, g);
+    return x == 0.0 ? 0.0 : g;  // rsq(0) = inf
+}
+// centre at the ray's time, shape.rs:96-98 (dc = 0 for a static sphere)
+__device__ __forceinline__ void sphere_centre_f64(const DevScene& S, int id, float time, double& cx, double& cy, double& cz) {
+    cx = (double)S.c0x[id]; cy = (double)S.c0y[id]; cz = (double)S.c0z[id];
+    if (S.any_moving) {  // wave-uniform
+        const double tm = (double)time;
+        cx += tm * (double)S.dcx[id]; cy += tm * (double)S.dcy[id]; cz += tm * (double)S.dcz[id];
+    }
+}
 __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
                                                double t_min, double t_max, bool clamp_disc, double& t_out) {
-    const double tm = (double)r.time;
-    const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];
-    const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
-    const double cz = (double)S.c0z[id] + tm * (double)S.dcz[id];
+    double cx, cy, cz;
+    sphere_centre_f64(S, id, r.time, cx, cy, cz);
     const double rad = (double)S.rad[id];
     const double ocx = (double)r.o.x - cx, ocy = (double)r.o.y - cy, ocz = (double)r.o.z - cz;
     const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
@@ -505,7 +537,7 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     double disc = hb * hb - a * c;
     if (clamp_disc && disc < 0.0 && disc > -1e-14 * hb * hb) disc = 0.0;  // f64 rounding only
     if (!(disc >= 0.0)) return false;
-    const double root = sqrt(disc);
+    const double root = sqrt_f64(disc);
     double t = (-hb - root) * inv_a;  // one f64 reciprocal per ray instead of a division per root
     bool ok = (t >= t_min) && (t < t_max);
     if (!ok) {
@@ -540,7 +572,7 @@ __device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, f
     w.t_best = inf;
     w.id_best = -1;
     const double a = dir_len2(r);
-    w.inv_a = 1.0 / a;
+    w.inv_a = rcp_f64(a);
     for (int k = 0; k < S.n_big; ++k) {  // big spheres, f64, world order
         double t;
         const int id = S.big_id[k];
@@ -580,10 +612,8 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     }
     // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
     const int id = w.id_best;
-    const double tm = (double)r.time;
-    const double cx = (double)S.c0x[id] + tm * (double)S.dcx[id];  // shape.rs:96-98 (dc = 0 for a static sphere)
-    const double cy = (double)S.c0y[id] + tm * (double)S.dcy[id];
-    const double cz = (double)S.c0z[id] + tm * (double)S.dcz[id];
+    double cx, cy, cz;
+    sphere_centre_f64(S, id, r.time, cx, cy, cz);
     const double px = (double)r.o.x + w.t_best * (double)r.d.x;
     const double py = (double)r.o.y + w.t_best * (double)r.d.y;
     const double pz = (double)r.o.z + w.t_best * (double)r.d.z;

@@ -176,9 +176,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 if (item < total) {
                     const ArgsPtr K = launder(K0);
-                    const uint32_t smp_i = item / npix;
-                    P.pix_local = item - smp_i * npix;
-                    const uint32_t ly = P.pix_local / tw, lx = P.pix_local - ly * tw;
+                    uint32_t smp_i, ly, lx;
+                    if (npix == kTile * kTile) {  // a full tile (wave-uniform): shifts instead of two 32-bit divisions
+                        smp_i = item >> 6; P.pix_local = item & 63;
+                        ly = P.pix_local >> 3; lx = P.pix_local & 7;
+                    } else {
+                        smp_i = item / npix; P.pix_local = item - smp_i * npix;
+                        ly = P.pix_local / tw; lx = P.pix_local - ly * tw;
+                    }
                     x = tx0 + lx; y = ty0 + ly;
                     P.pix = y * K->W + x;
                     P.smp = K->spp_first + s_lo + smp_i;
@@ -255,7 +260,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                     for (int k = 0; k < 3; ++k) {
                         float v = c[k];
                         v = (v > 0.0f) ? fminf(v, 1048576.0f) : 0.0f;  // NaN / negative -> 0
-                        const unsigned long long q = (unsigned long long)(v * kTwoPow32);
+                        // trunc(v * 2^32) from two 32-bit conversions: the integer part, then the (exact) rest
+                        const uint32_t whole = (uint32_t)v;
+                        const unsigned long long q = ((unsigned long long)whole << 32) | (uint32_t)((v - (float)whole) * kTwoPow32);
                         if (q) {
                             if (P.orphan) atomicAdd(A.accum + (size_t)P.pix * 3 + k, q);
                             else atomicAdd(&acc[P.pix_local * 3 + k], q);
@@ -842,6 +849,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     D.n_fused = (int32_t)fused.size();
     D.n_spheres = (int32_t)s->n_spheres;
     D.n_textures = (int32_t)s->n_textures;
+    D.any_moving = 0;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) D.any_moving |= (s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) ? 1 : 0;
     c->S = D;
     c->lds_scene = align16(lds_need);
     c->has_noise = false;
