@@ -19,6 +19,11 @@ int rt_debug_set_work_units(rt_ctx* ctx, uint32_t unit_a, uint32_t unit_b, int32
  * along a Morton curve (A/B switch for the lazy root extraction; results are identical). */
 int rt_debug_set_scan_order(rt_ctx* ctx, int world_order);
 
+/* n = 1 or 2: the next rt_upload_scene gives every wave that many tile buffers in LDS (2: the in-flight paths of a
+ * finished work unit keep adding into their tile's LDS sums; 1: they add straight into the global accumulators) when
+ * that many fit; 0 restores the choice by LDS room and occupancy.  Results are identical. */
+int rt_debug_set_tile_buffers(rt_ctx* ctx, int n);
+
 #ifdef __cplusplus
 }
 #endif

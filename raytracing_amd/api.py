@@ -115,7 +115,7 @@ ABI_SYMBOLS = [
     "rt_multi_upload_scene", "rt_multi_render", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
-    "rt_debug_set_work_units", "rt_debug_set_scan_order",
+    "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers",
 ]
 
 _lib = None
@@ -156,6 +156,7 @@ def load() -> C.CDLL:
     lib.rt_render_accum_device_noalloc.argtypes = [vp, C.POINTER(Camera), C.POINTER(Params), vp, C.POINTER(Stats)]
     lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
     lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
+    lib.rt_debug_set_tile_buffers.argtypes = [vp, C.c_int]
     lib.rt_intersect_batch.argtypes = [vp, vp, C.c_uint32, C.c_float, vp]
     lib.rt_scatter_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, vp]
     lib.rt_texture_batch.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp]
@@ -404,6 +405,10 @@ class Context:
     def debug_set_work_units(self, unit_a: int = 0, unit_b: int = 0, tail_span: int = -1):
         """include/rtx_hip_debug.h: force the work-unit schedule (0, 0, -1 = defaults)."""
         self._check(self.lib.rt_debug_set_work_units(self._h, unit_a, unit_b, tail_span))
+
+    def debug_set_tile_buffers(self, n: int = 0):
+        """include/rtx_hip_debug.h: LDS tile buffers per wave from the next upload on (0 = chosen by the library)."""
+        self._check(self.lib.rt_debug_set_tile_buffers(self._h, n))
 
     def debug_set_scan_order(self, world_order: bool):
         self._check(self.lib.rt_debug_set_scan_order(self._h, 1 if world_order else 0))

@@ -59,6 +59,7 @@ struct RenderArgs {
     uint32_t k0, k1;
     float t_min;
     uint32_t lds_scene_bytes;
+    uint32_t acc_bufs;       // tile accumulators per wave in LDS: 2 (current + previous tile) when they fit, else 1
     unsigned long long* accum;  // W*H*3 fixed-point (2^-32) radiance sums
     unsigned long long* rays;
     unsigned int* unit_counter;  // next unclaimed work unit (zeroed before the launch)
@@ -70,21 +71,36 @@ struct RenderArgs {
 // TWO paths (the packed scan tests both against each sphere in one instruction stream).  Inside a unit the wave
 // runs a private queue of (pixel, sample) items: a path slot whose path ended takes the next item, and when the
 // unit's items run out the wave claims the next unit WITHOUT draining: paths of the old unit still in flight
-// finish as "orphans" that add straight into the global accumulators.  Radiance is summed in 2^-32 fixed point
-// (order-independent => bit-reproducible images whatever the chunking, tiling or scheduling): LDS per wave and
-// tile, then one global atomic per pixel-channel at the end of a unit.
+// keep adding into their tile's LDS sums, which the wave holds for one more unit (TWO tile buffers per wave, current
+// and previous: a unit lasts ~65 passes, so nearly every straggler ends while its tile is still "previous"); a path
+// that outlives even that, or a scene whose noise tables leave LDS room for one buffer only, adds straight into
+// the global accumulators (an "orphan").  Radiance is summed in 2^-32 fixed point (order-independent =>
+// bit-reproducible images whatever the chunking, tiling or scheduling): LDS per wave and tile, then one global
+// atomic per pixel-channel when the tile's buffer is retired.  (With one buffer the in-flight paths of every
+// finished unit, ~all 128 slots, were orphans: two thirds of the kernel's HBM traffic.)
 struct PathState {
     Ray ray;
     f3 thr;
-    uint32_t pix_local, pix, smp, depth;
-    bool alive, orphan;
+    uint32_t acc_idx;  // where its radiance goes: the LDS element of its pixel's R sum (tile buffer + 3 * pixel in tile), or kOrphan
+    uint32_t pix, smp, depth;
+    bool alive;
 };
+constexpr uint32_t kTileAcc = kTile * kTile * 3;  // u64 sums of one tile
+constexpr uint32_t kOrphan = 0xFFFFFFFFu;         // PathState::acc_idx of a path whose tile buffer was retired: global atomics
+// dynamic LDS after the noise tables, per wave: acc_bufs tile buffers, then the previous tile's geometry (4 words)
+__host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (size_t)acc_bufs * kTileAcc * sizeof(unsigned long long) + 16; }
 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 3  // ~144 VGPRs, no scratch.  4 waves per SIMD (128 VGPRs) measure +2 % but spill 22 dwords per
                            // lane, i.e. tens of GB of scratch writes per launch; 2 waves measure -1 %
 #endif
-template <bool kNoise>
+// Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
+#ifdef RT_CENSUS
+#define RT_MARK(name) asm volatile("; RT_MARK " name)
+#else
+#define RT_MARK(name)
+#endif
+template <bool kNoise, bool kTwoBufs>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
     // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
     // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
@@ -94,14 +110,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
     const ArgsPtr K0 = (ArgsPtr)__builtin_amdgcn_kernarg_segment_ptr();  // A_kernarg is the only argument: offset 0
     const RenderArgs& A = A_kernarg;
     extern __shared__ __align__(16) unsigned char lds[];
+    constexpr uint32_t kBufs = kTwoBufs ? 2 : 1;  // == RenderArgs::acc_bufs (the host picks the variant)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const LdsScene L = stage_scene(A.S, lds, tid, kBlock);
-    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes) + wave * 192;  // wave-private
-    acc[lane] = 0; acc[lane + 64] = 0; acc[lane + 128] = 0;
+    unsigned long long* acc = reinterpret_cast<unsigned long long*>(lds + A.lds_scene_bytes + wave * wave_lds_bytes(kBufs));  // wave-private
+    uint32_t* prev_geo = reinterpret_cast<uint32_t*>(acc + kBufs * kTileAcc);  // {tx0, ty0, tw, npix} of the previous tile
+    for (uint32_t e = lane; e < kBufs * kTileAcc; e += 64) acc[e] = 0;
+    if (lane < 4) prev_geo[lane] = lane == 2 ? 1u : 0u;
 
-    // current unit (wave-uniform)
+    // current unit (wave-uniform); cur_off: the current tile's buffer (the previous tile's is the other one)
     uint32_t tx0 = 0, ty0 = 0, tw = 1, npix = 0, s_lo = 0;
+    uint32_t cur_off = 0;
     uint32_t next = 0, total = 0;
     bool more = true;  // the unit queue may still hold work
 
@@ -110,34 +130,44 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
     for (int s = 0; s < 2; ++s) {
         ps[s].ray = {{0, 0, 0}, {0, 0, 1}, 0};
         ps[s].thr = {1, 1, 1};
-        ps[s].pix_local = ps[s].pix = ps[s].smp = ps[s].depth = 0;
-        ps[s].alive = ps[s].orphan = false;
+        ps[s].pix = ps[s].smp = ps[s].depth = 0;
+        ps[s].acc_idx = kOrphan;
+        ps[s].alive = false;
     }
     unsigned long long n_rays = 0;
     HitRec h[2];  // closest hits of the previous pass (consumed by the scatter at the top of the next one)
     h[0].sphere = h[1].sphere = -1;
 
-    // the unit's tile: LDS sums -> global accumulators, LDS cleared (the region is private to this wave)
-    auto flush_tile = [&]() {
+    // a tile's buffer: LDS sums -> global accumulators, LDS cleared (the region is private to this wave)
+    auto flush_tile = [&](uint32_t off, uint32_t fx0, uint32_t fy0, uint32_t fw, uint32_t fnpix) {
         // the tile's 3*npix sums are row-major in LDS; lanes take consecutive elements so that the atomics of one
         // instruction fall on consecutive addresses of (at most three) image rows
-        const uint32_t row = tw * 3, n = npix * 3;
+        const uint32_t row = fw * 3, n = fnpix * 3;
         for (uint32_t e = lane; e < n; e += 64) {
-            const unsigned long long q = acc[e];
+            const unsigned long long q = acc[off + e];
             if (q) {
                 const uint32_t ly = e / row, rem = e - ly * row;
-                atomicAdd(A.accum + ((size_t)(ty0 + ly) * A.W + tx0) * 3 + rem, q);
-                acc[e] = 0;
+                atomicAdd(A.accum + ((size_t)(fy0 + ly) * A.W + fx0) * 3 + rem, q);
+                acc[off + e] = 0;
             }
         }
     };
 
     for (;;) {
         // ---- unit queue: claim the next unit once this one has no items left and a slot is free
+        RT_MARK("claim");
         if (next >= total && more && __ballot(!ps[0].alive || !ps[1].alive) != 0ull) {
-            flush_tile();
-            ps[0].orphan = ps[0].alive;
-            ps[1].orphan = ps[1].alive;
+            // retire the OLDER buffer (the previous tile's; with one buffer, the current one): its sums go out, paths
+            // of it still in flight become orphans; the current tile becomes the previous one and keeps its buffer
+            constexpr bool two = kTwoBufs;
+            const uint32_t old_off = two ? kTileAcc - cur_off : 0u;
+            if (two) flush_tile(old_off, __builtin_amdgcn_readfirstlane(prev_geo[0]), __builtin_amdgcn_readfirstlane(prev_geo[1]),
+                                __builtin_amdgcn_readfirstlane(prev_geo[2]), __builtin_amdgcn_readfirstlane(prev_geo[3]));
+            else flush_tile(0u, tx0, ty0, tw, npix);
+            if (ps[0].acc_idx - old_off < kTileAcc) ps[0].acc_idx = kOrphan;  // (kOrphan - old_off wraps far above kTileAcc)
+            if (ps[1].acc_idx - old_off < kTileAcc) ps[1].acc_idx = kOrphan;
+            if (lane == 0) { prev_geo[0] = tx0; prev_geo[1] = ty0; prev_geo[2] = tw; prev_geo[3] = npix; }
+            cur_off = old_off;  // the buffer just emptied takes the next tile
             uint32_t u = 0;
             if (lane == 0) u = atomicAdd(A.unit_counter, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
@@ -167,6 +197,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             PathState& P = ps[s];
             // a slot whose nominee the f64 test rejected in the previous pass (h[s].sphere == kRetry) keeps its ray
             // and is traced again below with that nominee's key as the scan floor: no scatter, no new random numbers
+            RT_MARK("refill");
             const bool retry = P.alive && h[s].sphere == kRetry;
             const unsigned long long need = __ballot(!P.alive);
             bool fresh = false;
@@ -176,14 +207,15 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                                                                        __builtin_amdgcn_mbcnt_lo((uint32_t)need, 0u));
                 if (item < total) {
                     const ArgsPtr K = launder(K0);
-                    uint32_t smp_i, ly, lx;
+                    uint32_t smp_i, pl, ly, lx;
                     if (npix == kTile * kTile) {  // a full tile (wave-uniform): shifts instead of two 32-bit divisions
-                        smp_i = item >> 6; P.pix_local = item & 63;
-                        ly = P.pix_local >> 3; lx = P.pix_local & 7;
+                        smp_i = item >> 6; pl = item & 63;
+                        ly = pl >> 3; lx = pl & 7;
                     } else {
-                        smp_i = item / npix; P.pix_local = item - smp_i * npix;
-                        ly = P.pix_local / tw; lx = P.pix_local - ly * tw;
+                        smp_i = item / npix; pl = item - smp_i * npix;
+                        ly = pl / tw; lx = pl - ly * tw;
                     }
+                    P.acc_idx = cur_off + pl * 3;
                     x = tx0 + lx; y = ty0 + ly;
                     P.pix = y * K->W + x;
                     P.smp = K->spp_first + s_lo + smp_i;
@@ -194,8 +226,10 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             next = min(next + (uint32_t)__popcll(need), total);
             if (fresh || (P.alive && !retry)) {
                 const ArgsPtr K = launder(K0);  // camera + image geometry: read here, not held across the pass
+                RT_MARK("philox");
                 uint32_t r[4];
                 philox4x32_10(K->k0, K->k1, P.pix, P.smp, fresh ? (uint32_t)DIM_PIXEL : DIM_BOUNCE0 + P.depth, 0u, r);
+                RT_MARK("camera");
                 if (fresh) {
                     const float ri = K->antialias ? u01(r[0]) : 0.0f;  // main.rs:76-80
                     const float rj = K->antialias ? u01(r[1]) : 0.0f;
@@ -210,20 +244,23 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                     P.ray = camera_ray(K->cam, ci, cj, u01(r[2]), u01(r[3]), ut);
                     P.thr = {1.0f, 1.0f, 1.0f};
                     P.alive = true;
-                    P.orphan = false;
+
                 } else {  // the path hit h[s] in the previous pass and goes on (main.rs:117-125)
+                    RT_MARK("scatter");
                     const f3 albedo = scatter<kNoise>(A.S, h[s], P.ray, u01(r[0]), u01(r[1]), noise_tex[s]);
                     P.thr = P.thr * albedo;  // main.rs:118
                     ++P.depth;
                 }
             }
         }
+        RT_MARK("noise");
         if (kNoise) {  // the two slots' noise textures in one packed evaluation at the hit points (= the new ray origins)
             float v0 = 1.0f, v1 = 1.0f;
             noise_pair(A.S, L.fused, noise_tex[0], noise_tex[1], ps[0].ray.o, ps[1].ray.o, v0, v1);
             ps[0].thr = ps[0].thr * v0;  // colour = white * value (material.rs:369-373, :529-533)
             ps[1].thr = ps[1].thr * v1;
         }
+        RT_MARK("loopctl");
         if (__ballot(ps[0].alive || ps[1].alive) == 0ull) {
             if (!more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
             continue;          // (next >= total here, so the next pass claims a unit or clears `more`)
@@ -234,14 +271,17 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             Hit2 x;
             const Floor fl = {ps[0].alive ? retry_key(h[0]) : -1, ps[1].alive ? retry_key(h[1]) : -1,
                               retry_slot(h[0]), retry_slot(h[1])};
+            RT_MARK("begin");
             closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
                 L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; L.stat_levels = K->S.lists.stat_levels; L.mov_levels = K->S.lists.mov_levels; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
+                RT_MARK("scan");
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
+            RT_MARK("end");
             closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
         }
         // ---- paths that end here: the sky (main.rs:133-138) or the depth budget (main.rs:126-130: black, and the
@@ -250,6 +290,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
+            RT_MARK("terminate");
             if (P.alive && h[s].sphere != kRetry) {  // (a rejected nominee: same ray segment again next pass)
                 ++n_rays;
                 if (h[s].sphere < 0) {
@@ -264,8 +305,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                         const uint32_t whole = (uint32_t)v;
                         const unsigned long long q = ((unsigned long long)whole << 32) | (uint32_t)((v - (float)whole) * kTwoPow32);
                         if (q) {
-                            if (P.orphan) atomicAdd(A.accum + (size_t)P.pix * 3 + k, q);
-                            else atomicAdd(&acc[P.pix_local * 3 + k], q);
+                            if (P.acc_idx == kOrphan) atomicAdd(A.accum + (size_t)P.pix * 3 + k, q);
+                            else atomicAdd(&acc[P.acc_idx + k], q);
                         }
                     }
                 } else if (P.depth + 1 == A.max_depth) {
@@ -274,11 +315,21 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             }
         }
     }
-    flush_tile();  // no-op unless the loop is ever left with a tile open
+    // the last tile (the final claim made it the previous one); the current buffer is empty unless the loop is ever left with a tile open
+    if (kTwoBufs) flush_tile(kTileAcc - cur_off, __builtin_amdgcn_readfirstlane(prev_geo[0]), __builtin_amdgcn_readfirstlane(prev_geo[1]),
+                                    __builtin_amdgcn_readfirstlane(prev_geo[2]), __builtin_amdgcn_readfirstlane(prev_geo[3]));
+    flush_tile(cur_off, tx0, ty0, tw, npix);
 
     // ray-segment counter: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off, 64);
     if (lane == 0 && n_rays) atomicAdd(A.rays, n_rays);
+}
+
+// the variant a scene runs: with or without the noise textures compiled in, two tile buffers per wave or one
+typedef void (*RenderKernel)(const RenderArgs);
+static RenderKernel render_variant(bool noise, bool two_bufs) {
+    return noise ? (two_bufs ? render_kernel<true, true> : render_kernel<true, false>)
+                 : (two_bufs ? render_kernel<false, true> : render_kernel<false, false>);
 }
 
 __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ out, size_t n,
@@ -439,6 +490,7 @@ struct rt_ctx {
     int cu_count = 256;
     bool has_noise = false;  // the uploaded scene references a value/Perlin noise texture
     int blocks_per_cu = 0;   // resident workgroups of the scene's render-kernel variant (computed at upload)
+    uint32_t acc_bufs = 1;   // LDS tile buffers per wave (RenderArgs::acc_bufs; computed at upload)
     // this device's copy of g_noalloc_scratch (hipGetSymbolAddress at rt_create) and a pinned word for the ray count
     unsigned long long* scratch = nullptr;
     unsigned long long* pinned_rays = nullptr;
@@ -446,6 +498,7 @@ struct rt_ctx {
     uint32_t dbg_unit_a = 0, dbg_unit_b = 0;
     int32_t dbg_tail_span = -1;
     bool dbg_world_order = false;
+    int dbg_tile_bufs = 0;
 };
 
 namespace {
@@ -855,11 +908,18 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     c->lds_scene = align16(lds_need);
     c->has_noise = false;
     for (uint32_t i = 0; i < s->n_textures; ++i) c->has_noise |= s->textures[i].kind >= RT_TEX_VALUE_NOISE;
-    // resident workgroups per CU of the variant this scene runs (the persistent grid is exactly that many)
-    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
-    c->blocks_per_cu = 0;
-    RT_HIP(c, c->has_noise ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->blocks_per_cu, render_kernel<true>, kBlock, lds_bytes)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&c->blocks_per_cu, render_kernel<false>, kBlock, lds_bytes));
+    // resident workgroups per CU of the variant this scene runs (the persistent grid is exactly that many), and
+    // the tile buffers per wave: two, unless the second one would not fit the 64 KiB of dynamic LDS next to the
+    // noise tables or would cost a resident workgroup
+    int occ[3] = {0, 0, 0};
+    for (uint32_t bufs = 1; bufs <= 2; ++bufs) {
+        const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(bufs);
+        if (lds_bytes > 65536) continue;
+        RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2), kBlock, lds_bytes));
+    }
+    c->acc_bufs = (occ[2] >= occ[1] && occ[2] > 0) ? 2 : 1;
+    if (c->dbg_tile_bufs && occ[c->dbg_tile_bufs] > 0) c->acc_bufs = (uint32_t)c->dbg_tile_bufs;  // rt_debug_set_tile_buffers
+    c->blocks_per_cu = occ[c->acc_bufs];
     c->has_scene = true;
     return RT_OK;
 }
@@ -901,9 +961,10 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
     A.t_min = p->t_min;
     A.lds_scene_bytes = (uint32_t)c->lds_scene;
+    A.acc_bufs = c->acc_bufs;
     A.accum = accum;
     A.rays = counters;
-    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * 192 * sizeof(unsigned long long);
+    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(c->acc_bufs);
 
     // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * n_levels work units that a grid of
     // persistent waves (as many as the GPU holds at once) pulls from a counter.  Launches are capped at 2^31
@@ -939,8 +1000,7 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
         A.unit_counter = reinterpret_cast<unsigned int*>(counters + 1);
         RT_HIP(c, hipMemsetAsync(counters + 1, 0, sizeof(unsigned long long), c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
-        if (noise) hipLaunchKernelGGL(render_kernel<true>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
-        else hipLaunchKernelGGL(render_kernel<false>, dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
+        hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
         done += spp_l;
         ++launches;
@@ -1029,6 +1089,11 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rg
 int rt_debug_set_work_units(rt_ctx* c, uint32_t unit_a, uint32_t unit_b, int32_t tail_span) {
     if (!c) return RT_ERR_BAD_ARG;
     c->dbg_unit_a = unit_a; c->dbg_unit_b = unit_b; c->dbg_tail_span = tail_span;
+    return RT_OK;
+}
+int rt_debug_set_tile_buffers(rt_ctx* c, int n) {
+    if (!c || n < 0 || n > 2) return RT_ERR_BAD_ARG;
+    c->dbg_tile_bufs = n;
     return RT_OK;
 }
 int rt_debug_set_scan_order(rt_ctx* c, int world_order) {

@@ -300,26 +300,32 @@ def test_baseline_configs_full_size_properties(ctx, api, name, W, H, spp, off):
 
 
 def test_work_unit_size_does_not_change_the_image(ctx, api):
-    """The persistent waves pull (tile, spp-chunk) units from a counter and switch units without draining (paths
-    of the old unit finish as orphans that add straight into the global sums). Whatever the unit size, which wave
-    ran a unit, or how many switches happened, the fixed-point sums - hence the image and the ray count - are
-    identical bit for bit. rt_debug_set_work_units (include/rtx_hip_debug.h) forces the samples per unit."""
+    """The persistent waves pull (tile, spp-chunk) units from a counter and switch units without draining: paths
+    of the old unit keep adding into their tile's LDS sums for one more unit (two tile buffers per wave), or, with one
+    buffer or when they outlive that too, finish as orphans that add straight into the global sums. Whatever the unit
+    size, the buffer count, which wave ran a unit, or how many switches happened, the fixed-point sums - hence the
+    image and the ray count - are identical bit for bit. rt_debug_set_work_units / rt_debug_set_tile_buffers
+    (include/rtx_hip_debug.h) force the samples per unit and the buffers per wave (1-sample units with 2 buffers:
+    most paths outlive two units, so all three destinations are in use)."""
     w = api.World("Random", seed=3, aspect=328 / 200)  # moving spheres + checker, ragged width (328 = 41 tiles)
     ctx.upload(w.scene)
     base = None
-    for unit in (0, 1, 7, 40, 1000):
+    for unit, bufs in ((0, 0), (1, 2), (1, 1), (7, 2), (7, 1), (40, 1), (1000, 2)):
         p = api.make_params(328, 200, 40, seed=w.render_seed)
         ctx.debug_set_work_units(unit, unit, 0 if unit else -1)
+        ctx.debug_set_tile_buffers(bufs)
         try:
+            ctx.upload(w.scene)
             img, st = ctx.render(w.camera, p)
         finally:
             ctx.debug_set_work_units()
+            ctx.debug_set_tile_buffers(0)
         if base is None:
             base = (img, st.rays_traced)
             assert np.isfinite(img).all() and st.samples == 328 * 200 * 40
         else:
-            assert np.array_equal(img, base[0]), f"unit={unit}"
-            assert st.rays_traced == base[1], f"unit={unit}"
+            assert np.array_equal(img, base[0]), f"unit={unit} bufs={bufs}"
+            assert st.rays_traced == base[1], f"unit={unit} bufs={bufs}"
 
 
 def test_multi_launch_render_matches_partition(ctx, api):

@@ -14,6 +14,9 @@ for scene in sys.argv[1:] or ["FinalStatic"]:
     img, st = ctx.render(w.camera, p)
     ctx.lib.rt_debug_counters(out, 1)
     g, gt, stk, r_useful, r_front, s_front, s_front_bound = [out[i] for i in range(7)]
+    # 0 member groups tested, 1 groups sent to root extraction, 2 spheres there, 3 ray-roots with disc >= 0,
+    # 5 bounds tested (all levels), 6 group bounds passed
+    print("raw", [int(out[i]) for i in range(8)], "rays", int(st.rays_traced))
     print("slot utilisation %.4f (rays %d, passes %d, kernel %.1f ms)" % (st.rays_traced / (g / (w.arrays()["radius"].shape[0] // 4 + 0.0) * 128), st.rays_traced, g, st.kernel_ms))
     print(scene, "groups", g, "taken %.3f" % (gt / g), "spheres taken / sphere %.3f" % (stk / (4 * g)),
           "per taken group %.2f" % (stk / max(gt, 1)), "useful ray-roots per taken sphere (of 128) %.2f" % (r_useful / max(stk, 1)),
