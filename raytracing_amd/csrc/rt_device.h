@@ -86,11 +86,19 @@ struct ScanLists {
     float cmax;             // max |c| over the static list, in the scan frame
     int32_t stat_levels, mov_levels;  // bit L >= 1 set: bound level L is worth testing for this list (upload decides)
 };
+// A "big" sphere as the per-ray f64 test reads it: the exact f64 images of the caller's fp32 numbers (r2 = r * r is
+// exact in f64), fetched with ONE scalar load per sphere (wave-uniform index) and used straight from SGPRs.
+struct BigSphere {
+    double cx, cy, cz, r2;
+    double dcx, dcy, dcz, inv_r;  // inv_r: 1/r rounded to fp32, as in DevScene::inv_rad
+};
+static_assert(sizeof(BigSphere) == 64, "BigSphere = one s_load_dwordx16");
 struct DevScene {
     ScanLists lists;
     const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
     // spheres too large for the fp32 scan (|c|,r >> 1: e.g. the r = 1000 ground): f64 test
     const int32_t* big_id;
+    const BigSphere* big;  // n_big records, in big_id order
     int32_t n_big;
     // world-order SoA for the f64 hit record of the winning sphere
     const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad, *inv_rad;
@@ -525,15 +533,12 @@ __device__ __forceinline__ void sphere_centre_f64(const DevScene& S, int id, flo
         cx += tm * (double)S.dcx[id]; cy += tm * (double)S.dcy[id]; cz += tm * (double)S.dcz[id];
     }
 }
-__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
-                                               double t_min, double t_max, bool clamp_disc, double& t_out) {
-    double cx, cy, cz;
-    sphere_centre_f64(S, id, r.time, cx, cy, cz);
-    const double rad = (double)S.rad[id];
+__device__ __forceinline__ bool sphere_roots_f64(double cx, double cy, double cz, double r2, const Ray& r, double a,
+                                                 double inv_a, double t_min, double t_max, bool clamp_disc, double& t_out) {
     const double ocx = (double)r.o.x - cx, ocy = (double)r.o.y - cy, ocz = (double)r.o.z - cz;
     const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
     const double hb = ocx * dx + ocy * dy + ocz * dz;
-    const double c = ocx * ocx + ocy * ocy + ocz * ocz - rad * rad;
+    const double c = ocx * ocx + ocy * ocy + ocz * ocz - r2;
     double disc = hb * hb - a * c;
     if (clamp_disc && disc < 0.0 && disc > -1e-14 * hb * hb) disc = 0.0;  // f64 rounding only
     if (!(disc >= 0.0)) return false;
@@ -547,6 +552,13 @@ __device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const 
     if (!ok) return false;
     t_out = t;
     return true;
+}
+__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
+                                               double t_min, double t_max, bool clamp_disc, double& t_out) {
+    double cx, cy, cz;
+    sphere_centre_f64(S, id, r.time, cx, cy, cz);
+    const double rad = (double)S.rad[id];
+    return sphere_roots_f64(cx, cy, cz, rad * rad, r, a, inv_a, t_min, t_max, clamp_disc, t_out);
 }
 
 // Per-ray state kept across the packed scan: the f64 big-sphere result before it, the f64 hit record after it.
@@ -567,23 +579,12 @@ constexpr float kScanInflate = 1.0f + 8.0f / 16777216.0f;
 __device__ __forceinline__ double dir_len2(const Ray& r) {
     return (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
 }
-__device__ __forceinline__ uint32_t hit_begin(const DevScene& S, const Ray& r, float t_min, HitWork& w) {
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
-    w.t_best = inf;
-    w.id_best = -1;
-    const double a = dir_len2(r);
-    w.inv_a = rcp_f64(a);
-    for (int k = 0; k < S.n_big; ++k) {  // big spheres, f64, world order
-        double t;
-        const int id = S.big_id[k];
-        if (sphere_hit_f64(S, id, r, a, w.inv_a, (double)t_min, w.t_best, false, t)) {
-            w.t_best = t; w.id_best = id;
-        }
-    }
+// the key bound a ray brings into the scan from its big-sphere hit (same inflated units as the scan's keys)
+__device__ __forceinline__ uint32_t hit_begin_key(const HitWork& w, double a, float t_min, float& inv_len) {
     const float len2 = (float)a;
-    w.inv_len = fast_rsq(len2) * kScanInflate;
+    inv_len = fast_rsq(len2) * kScanInflate;
     if (w.id_best < 0) return kInfBits;
-    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * w.inv_len));  // same (inflated) units as the keys
+    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * inv_len));
     return __float_as_uint(fmaxf(tb, 0.0f));
 }
 // HitRec::sphere == kRetry: the scan's nominee (key = bits of HitRec::t) was a false positive of the conservative
@@ -649,11 +650,33 @@ struct Hit2 {
 };
 __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                               float t_min, Hit2& x) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
     x.best_a = x.best_b = kInfBits;
     x.wa.id_best = x.wb.id_best = -1;
     x.wa.inv_len = x.wb.inv_len = 1.0f;
-    if (do_a) x.best_a = hit_begin(S, ra, t_min, x.wa);
-    if (do_b) x.best_b = hit_begin(S, rb, t_min, x.wb);
+    x.wa.t_best = x.wb.t_best = inf;
+    const double aa = dir_len2(ra), ab = dir_len2(rb);
+    x.wa.inv_a = rcp_f64(aa);
+    x.wb.inv_a = rcp_f64(ab);
+    {  // big spheres, f64, world order: one scalar load per sphere serves both rays
+        typedef double d8 __attribute__((ext_vector_type(8)));
+        const RT_AS4 d8* big = (const RT_AS4 d8*)(uintptr_t)S.big;
+        const RT_AS4 int32_t* big_id = (const RT_AS4 int32_t*)(uintptr_t)S.big_id;
+        for (int k = 0; k < S.n_big; ++k) {
+            const d8 B = big[k];  // {cx, cy, cz, r2, dcx, dcy, dcz, inv_r}
+            const int id = big_id[k];
+            const bool moving = S.any_moving;
+            auto test = [&](const Ray& r, double a, HitWork& w) {
+                double cx = B[0], cy = B[1], cz = B[2], t;
+                if (moving) { const double tm = (double)r.time; cx += tm * B[4]; cy += tm * B[5]; cz += tm * B[6]; }
+                if (sphere_roots_f64(cx, cy, cz, B[3], r, a, w.inv_a, (double)t_min, w.t_best, false, t)) { w.t_best = t; w.id_best = id; }
+            };
+            if (do_a) test(ra, aa, x.wa);
+            if (do_b) test(rb, ab, x.wb);
+        }
+    }
+    if (do_a) x.best_a = hit_begin_key(x.wa, aa, t_min, x.wa.inv_len);
+    if (do_b) x.best_b = hit_begin_key(x.wb, ab, t_min, x.wb.inv_len);
     Pair& p = x.p;
     p.dx = f2{ra.d.x * x.wa.inv_len, rb.d.x * x.wb.inv_len};
     p.dy = f2{ra.d.y * x.wa.inv_len, rb.d.y * x.wb.inv_len};

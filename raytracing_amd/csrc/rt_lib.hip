@@ -50,6 +50,7 @@ struct RenderArgs {
     DevScene S;
     rt_camera cam;
     uint32_t W, H, tiles_x, n_tiles;
+    float inv_wm1, inv_hm1;  // 1 / (W - 1), 1 / (H - 1) in fp32 (main.rs:81-82), divided once on the host
     uint32_t spp_first;      // absolute index of this launch's first sample
     uint32_t spp_count;      // samples per pixel in this launch
     uint32_t spp_a, n_a, spp_b;  // chunk k < n_a covers samples [k*spp_a, (k+1)*spp_a); later chunks are spp_b wide
@@ -233,8 +234,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 if (fresh) {
                     const float ri = K->antialias ? u01(r[0]) : 0.0f;  // main.rs:76-80
                     const float rj = K->antialias ? u01(r[1]) : 0.0f;
-                    const float ci = ((float)x + ri) * (1.0f / ((float)K->W - 1.0f));           // main.rs:81
-                    const float cj = 1.0f - ((float)y + rj) * (1.0f / ((float)K->H - 1.0f));    // main.rs:82
+                    const float ci = ((float)x + ri) * K->inv_wm1;           // main.rs:81
+                    const float cj = 1.0f - ((float)y + rj) * K->inv_hm1;    // main.rs:82
                     float ut = 0.0f;
                     if (K->cam.has_shutter) {
                         uint32_t r1[4];
@@ -880,6 +881,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
+    std::vector<BigSphere> big(big_id.size());
+    for (size_t k = 0; k < big_id.size(); ++k) {
+        const int32_t i = big_id[k];
+        big[k] = {(double)s->c0x[i], (double)s->c0y[i], (double)s->c0z[i], (double)s->radius[i] * (double)s->radius[i],
+                  (double)s->dcx[i], (double)s->dcy[i], (double)s->dcz[i], (double)inv_rad[i]};
+    }
+    UP(dev_copy(c, big.data(), big.size(), &D.big));
     UP(dev_copy(c, s->c0x, (size_t)s->n_spheres, &D.c0x));
     UP(dev_copy(c, s->c0y, (size_t)s->n_spheres, &D.c0y));
     UP(dev_copy(c, s->c0z, (size_t)s->n_spheres, &D.c0z));
@@ -954,6 +962,8 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
     A.S = c->S;
     A.cam = *cam;
     A.W = p->width; A.H = p->height;
+    A.inv_wm1 = 1.0f / ((float)p->width - 1.0f);  // IEEE fp32 division, as the kernel did per sample
+    A.inv_hm1 = 1.0f / ((float)p->height - 1.0f);
     A.tiles_x = (p->width + kTile - 1) / kTile;
     A.n_tiles = A.tiles_x * ((p->height + kTile - 1) / kTile);
     A.max_depth = p->max_depth;
