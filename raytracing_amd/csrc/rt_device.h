@@ -93,6 +93,19 @@ struct BigSphere {
     double dcx, dcy, dcz, inv_r;  // inv_r: 1/r rounded to fp32, as in DevScene::inv_rad
 };
 static_assert(sizeof(BigSphere) == 64, "BigSphere = one s_load_dwordx16");
+// What scatter reads for the sphere a path hit, flattened per sphere (48 B, three 16-byte loads in ONE round trip
+// instead of the chain sphere -> material id -> material -> texture): the material and, for a Lambertian, its solid /
+// checker texture (material.rs:125-165).  A Lambertian with a noise texture carries the texture's id instead.
+struct ShadeRec {
+    int32_t type;       // RT_MAT_*
+    float fuzz, ior;
+    int32_t noise_tex;  // >= 0: Lambertian whose albedo is noise texture `noise_tex` (white times its value)
+    float a[3];         // Metal: albedo; Lambertian: colour of a solid texture / odd colour of a checker
+    int32_t kind;       // RT_TEX_SOLID or RT_TEX_CHECKER
+    float b[3];         // even colour of a checker
+    float freq_turns;   // checker frequency / 2 pi
+};
+static_assert(sizeof(ShadeRec) == 48, "ShadeRec layout");
 struct DevScene {
     ScanLists lists;
     const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
@@ -103,7 +116,7 @@ struct DevScene {
     // world-order SoA for the f64 hit record of the winning sphere
     const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad, *inv_rad;
     const uint32_t* mat_id;
-    const rt_material* mats;
+    const ShadeRec* shade;   // world order
     const DevTexture* texs;
     const FusedNoise* fused;  // n_fused images, copied to LDS by every workgroup that evaluates textures
     int32_t n_fused;
@@ -873,7 +886,7 @@ __device__ __forceinline__ float schlick(float cosv, float eta) {  // material.r
 // texture (upload knows) run the variant whose register budget is not set by the noise code.
 template <bool kNoise = true>
 __device__ inline f3 scatter(const DevScene& S, const HitRec& h, Ray& r, float u0, float u1, int& noise_tex) {
-    const rt_material m = S.mats[S.mat_id[h.sphere]];
+    const ShadeRec m = S.shade[h.sphere];
     const f3 ud = normalize(r.d);
     const float dn = dot(ud, h.n);
     f3 albedo, dir;
@@ -895,15 +908,22 @@ __device__ inline f3 scatter(const DevScene& S, const HitRec& h, Ray& r, float u
         if (m.type == RT_MAT_LAMBERTIAN) {  // material.rs:36-41
             dir = h.n + sph;
             if (dot(dir, dir) < 1e-12f) dir = h.n;  // degenerate-direction guard (deviations)
-            if (!texture_simple(S, m.texture_id, h.p, albedo)) {
+            // Texture::value for a solid or a checker (material.rs:155-165; see texture_simple), straight-line
+            const float ft = m.freq_turns;
+            bool parity = __builtin_amdgcn_fractf(h.p.x * ft) > 0.5f;
+            parity ^= __builtin_amdgcn_fractf(h.p.y * ft) > 0.5f;
+            parity ^= __builtin_amdgcn_fractf(h.p.z * ft) > 0.5f;
+            const bool a = m.kind == RT_TEX_SOLID || parity;
+            albedo = {a ? m.a[0] : m.b[0], a ? m.a[1] : m.b[1], a ? m.a[2] : m.b[2]};
+            if (m.noise_tex >= 0) {
                 albedo = {1.0f, 1.0f, 1.0f};
-                if (kNoise) noise_tex = m.texture_id;  // unreachable otherwise: that variant only runs noise-free scenes
+                if (kNoise) noise_tex = m.noise_tex;  // unreachable otherwise: that variant only runs noise-free scenes
             }
         } else {  // material.rs:61-72
             const f3 fz = sph * m.fuzz;
             dir = reflect_unit(ud, h.n) + fz;
             if (dot(dir, h.n) <= 0.0f) dir = dir - fz * 2.0f;
-            albedo = {m.albedo[0], m.albedo[1], m.albedo[2]};
+            albedo = {m.a[0], m.a[1], m.a[2]};
         }
     }
     r.o = h.p;

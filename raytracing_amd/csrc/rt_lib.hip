@@ -897,7 +897,25 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, s->radius, (size_t)s->n_spheres, &D.rad));
     UP(dev_copy(c, inv_rad.data(), inv_rad.size(), &D.inv_rad));
     UP(dev_copy(c, s->material_id, (size_t)s->n_spheres, &D.mat_id));
-    UP(dev_copy(c, s->materials, (size_t)s->n_materials, &D.mats));
+    std::vector<ShadeRec> shade(s->n_spheres);
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {
+        const rt_material& m = s->materials[s->material_id[i]];
+        ShadeRec& q = shade[i];
+        q = ShadeRec{m.type, m.fuzz, m.ior, -1, {1.0f, 1.0f, 1.0f}, RT_TEX_SOLID, {1.0f, 1.0f, 1.0f}, 0.0f};
+        if (m.type == RT_MAT_METAL) {
+            for (int k = 0; k < 3; ++k) q.a[k] = m.albedo[k];
+        } else if (m.type == RT_MAT_LAMBERTIAN) {
+            const rt_texture& t = s->textures[m.texture_id];
+            if (t.kind == RT_TEX_SOLID || t.kind == RT_TEX_CHECKER) {
+                for (int k = 0; k < 3; ++k) { q.a[k] = t.color_a[k]; q.b[k] = t.color_b[k]; }
+                q.kind = t.kind;
+                q.freq_turns = texs[m.texture_id].freq_turns;
+            } else {
+                q.noise_tex = m.texture_id;
+            }
+        }
+    }
+    UP(dev_copy(c, shade.data(), shade.size(), &D.shade));
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
     UP(dev_copy(c, fused.data(), fused.size(), &D.fused));
 #undef UP
