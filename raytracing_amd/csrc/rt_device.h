@@ -113,8 +113,12 @@ struct DevScene {
     const int32_t* big_id;
     const BigSphere* big;  // n_big records, in big_id order
     int32_t n_big;
-    // world-order SoA for the f64 hit record of the winning sphere
-    const float *c0x, *c0y, *c0z, *dcx, *dcy, *dcz, *rad, *inv_rad;
+    // the nominee's f64 decision reads these in SCAN-SLOT order (no id indirection): {c0x, c0y, c0z, r}, {dcx, dcy, dcz, 0}
+    const float4* slot_a;
+    const float4* slot_dc;
+    // the f64 hit record of the winning sphere reads these in world order: {c0x, c0y, c0z, 1/r rounded to fp32}, {dcx, dcy, dcz, 0}
+    const float4* rec_a;
+    const float4* rec_dc;
     const uint32_t* mat_id;
     const ShadeRec* shade;   // world order
     const DevTexture* texs;
@@ -538,12 +542,15 @@ __device__ __forceinline__ double sqrt_f64(double x) {
     g = __builtin_fma(d, h, g);
     return x == 0.0 ? 0.0 : g;  // rsq(0) = inf
 }
-// centre at the ray's time, shape.rs:96-98 (dc = 0 for a static sphere)
-__device__ __forceinline__ void sphere_centre_f64(const DevScene& S, int id, float time, double& cx, double& cy, double& cz) {
-    cx = (double)S.c0x[id]; cy = (double)S.c0y[id]; cz = (double)S.c0z[id];
+// centre at the ray's time, shape.rs:96-98 (dc = 0 for a static sphere), from one 16-byte record {c0, .} (+ {dc, .})
+__device__ __forceinline__ void sphere_centre_f64(const DevScene& S, const float4* c0, const float4* dc, int i, float time,
+                                                  double& cx, double& cy, double& cz, float& w) {
+    const v4f a = *reinterpret_cast<const v4f*>(c0 + i);
+    cx = (double)a.x; cy = (double)a.y; cz = (double)a.z; w = a.w;
     if (S.any_moving) {  // wave-uniform
+        const v4f m = *reinterpret_cast<const v4f*>(dc + i);
         const double tm = (double)time;
-        cx += tm * (double)S.dcx[id]; cy += tm * (double)S.dcy[id]; cz += tm * (double)S.dcz[id];
+        cx += tm * (double)m.x; cy += tm * (double)m.y; cz += tm * (double)m.z;
     }
 }
 __device__ __forceinline__ bool sphere_roots_f64(double cx, double cy, double cz, double r2, const Ray& r, double a,
@@ -566,14 +573,6 @@ __device__ __forceinline__ bool sphere_roots_f64(double cx, double cy, double cz
     t_out = t;
     return true;
 }
-__device__ __forceinline__ bool sphere_hit_f64(const DevScene& S, int id, const Ray& r, double a, double inv_a,
-                                               double t_min, double t_max, bool clamp_disc, double& t_out) {
-    double cx, cy, cz;
-    sphere_centre_f64(S, id, r.time, cx, cy, cz);
-    const double rad = (double)S.rad[id];
-    return sphere_roots_f64(cx, cy, cz, rad * rad, r, a, inv_a, t_min, t_max, clamp_disc, t_out);
-}
-
 // Per-ray state kept across the packed scan: the f64 big-sphere result before it, the f64 hit record after it.
 // Kept small (7 VGPRs per ray): everything else is recomputed after the scan from the ray and the winner's id.
 struct HitWork {
@@ -611,8 +610,10 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     HitRec h;
     if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
         const int id = S.scan_id[slot];
-        double t;
-        if (id >= 0 && sphere_hit_f64(S, id, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t)) {
+        double cx, cy, cz, t;
+        float rad;
+        sphere_centre_f64(S, S.slot_a, S.slot_dc, slot, r.time, cx, cy, cz, rad);
+        if (id >= 0 && sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t)) {
             if (t < w.t_best) { w.t_best = t; w.id_best = id; }  // else a big sphere is closer: it keeps the hit
         } else {
             h.sphere = kRetry; h.front = slot; h.t = __uint_as_float(best); h.p = {0, 0, 0}; h.n = {0, 0, 0};
@@ -627,11 +628,12 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
     const int id = w.id_best;
     double cx, cy, cz;
-    sphere_centre_f64(S, id, r.time, cx, cy, cz);
+    float inv_rad;  // 1/r rounded to fp32: |n| = 1 +- 6e-8
+    sphere_centre_f64(S, S.rec_a, S.rec_dc, id, r.time, cx, cy, cz, inv_rad);
     const double px = (double)r.o.x + w.t_best * (double)r.d.x;
     const double py = (double)r.o.y + w.t_best * (double)r.d.y;
     const double pz = (double)r.o.z + w.t_best * (double)r.d.z;
-    const double ir = (double)S.inv_rad[id];  // 1/r rounded to fp32: |n| = 1 +- 6e-8
+    const double ir = (double)inv_rad;
     double nx = (px - cx) * ir, ny = (py - cy) * ir, nz = (pz - cz) * ir;
     const bool front = ((double)r.d.x * nx + (double)r.d.y * ny + (double)r.d.z * nz) < 0.0;
     if (!front) { nx = -nx; ny = -ny; nz = -nz; }

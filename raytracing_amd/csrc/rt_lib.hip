@@ -888,14 +888,23 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
                   (double)s->dcx[i], (double)s->dcy[i], (double)s->dcz[i], (double)inv_rad[i]};
     }
     UP(dev_copy(c, big.data(), big.size(), &D.big));
-    UP(dev_copy(c, s->c0x, (size_t)s->n_spheres, &D.c0x));
-    UP(dev_copy(c, s->c0y, (size_t)s->n_spheres, &D.c0y));
-    UP(dev_copy(c, s->c0z, (size_t)s->n_spheres, &D.c0z));
-    UP(dev_copy(c, s->dcx, (size_t)s->n_spheres, &D.dcx));
-    UP(dev_copy(c, s->dcy, (size_t)s->n_spheres, &D.dcy));
-    UP(dev_copy(c, s->dcz, (size_t)s->n_spheres, &D.dcz));
-    UP(dev_copy(c, s->radius, (size_t)s->n_spheres, &D.rad));
-    UP(dev_copy(c, inv_rad.data(), inv_rad.size(), &D.inv_rad));
+    {  // the 16-byte records of the f64 decision (scan-slot order) and of the hit record (world order)
+        std::vector<float4> slot_a(scan_id.size(), make_float4(0, 0, 0, 0)), slot_dc(slot_a), rec_a(s->n_spheres), rec_dc(s->n_spheres);
+        for (size_t k = 0; k < scan_id.size(); ++k) {
+            const int32_t i = scan_id[k];
+            if (i < 0) continue;  // a pad: never nominated
+            slot_a[k] = make_float4(s->c0x[i], s->c0y[i], s->c0z[i], s->radius[i]);
+            slot_dc[k] = make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f);
+        }
+        for (uint32_t i = 0; i < s->n_spheres; ++i) {
+            rec_a[i] = make_float4(s->c0x[i], s->c0y[i], s->c0z[i], inv_rad[i]);
+            rec_dc[i] = make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f);
+        }
+        UP(dev_copy(c, slot_a.data(), slot_a.size(), &D.slot_a));
+        UP(dev_copy(c, slot_dc.data(), slot_dc.size(), &D.slot_dc));
+        UP(dev_copy(c, rec_a.data(), rec_a.size(), &D.rec_a));
+        UP(dev_copy(c, rec_dc.data(), rec_dc.size(), &D.rec_dc));
+    }
     UP(dev_copy(c, s->material_id, (size_t)s->n_spheres, &D.mat_id));
     std::vector<ShadeRec> shade(s->n_spheres);
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
