@@ -65,7 +65,9 @@ def roofline_of(model, rays, samples, kernel_ms, launches):
     scenes) the texture arithmetic of every hit (hits = rays - samples: each path ends with exactly one miss)."""
     flops = rays * model["flops_per_ray"] + max(rays - samples, 0) * model["flops_per_noise_hit"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12
-    return {"bound": "valu", "kernel": "render_kernel<%s>" % ("true" if model["flops_per_noise_hit"] else "false"),
+    # template arguments as rocprofv3 prints them: <noise textures compiled in, two LDS tile buffers per wave>; the second
+    # is true for every scene with fewer than five fused noise tables, i.e. for all of BASELINE's
+    return {"bound": "valu", "kernel": "render_kernel<%s, true>" % ("true" if model["flops_per_noise_hit"] else "false"),
             "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_VALU_PEAK_TFLOPS, "flops_per_ray": model["flops_per_ray"],
             "flops_per_noise_hit": model["flops_per_noise_hit"],
