@@ -398,6 +398,43 @@ def test_caller_built_scenes_up_to_the_limit(ctx, api, orc, n, moving_every):
     assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
 
 
+def test_several_big_spheres_one_of_them_moving(ctx, api, orc):
+    """The per-ray f64 list with more than one entry and with motion: a ground (r = 1000), a static r = 40 dome and
+    an r = 30 sphere that MOVES during the shutter, over 60 small spheres (8 of them moving).  The big spheres are
+    read as f64 records with scalar loads (BigSphere, rt_device.h): world order among them, the time-interpolated
+    centre, and the hit record of whichever holds the hit are all compared with the oracle."""
+    rng = np.random.default_rng(21)
+    n_small = 60
+    c0 = np.zeros((n_small + 3, 3), np.float32)
+    rad = np.zeros(n_small + 3, np.float32)
+    dc = np.zeros((n_small + 3, 3), np.float32)
+    c0[0], rad[0] = (0, -1000, 0), 1000
+    c0[1], rad[1] = (-60, 20, -40), 40
+    c0[2], rad[2], dc[2] = (50, 25, -30), 30, (6, 3, -2)
+    c0[3:, 0] = rng.uniform(-10, 10, n_small); c0[3:, 1] = 0.3; c0[3:, 2] = rng.uniform(-10, 10, n_small)
+    rad[3:] = rng.uniform(0.2, 0.4, n_small).astype(np.float32)
+    dc[3:11, 1] = rng.uniform(0.1, 0.5, 8).astype(np.float32)
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_METAL, (0.8, 0.6, 0.2), 0.1, 0, 0),
+            (api.RT_MAT_DIELECTRIC, (1, 1, 1), 0, 1.5, 0)]
+    mid = (np.arange(n_small + 3) % 3).astype(np.uint32)
+    mid[0] = 0
+    fs = api.FlatScene(c0, rad, mid, mats, [api.solid_texture((0.5, 0.6, 0.4))], dc=dc)
+    ctx.upload(fs.scene)
+    cam = api.camera_build((20, 6, 30), (0, 5, 0), vfov_degrees=70.0, aspect_ratio=96 / 64, aperture=0.05,
+                           focus_dist=30.0, shutter=(0.0, 1.0))
+    rays = ctx.camera_rays(cam, rng.random((16384, 2), dtype=np.float32), rng.random((16384, 4), dtype=np.float32))
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(fs.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
+    hit_ids = exp["sphere_id"][exp["hit"] == 1]
+    print(st, "hits per big sphere", [int((hit_ids == k).sum()) for k in range(3)], "small", int((hit_ids >= 3).sum()))
+    assert all((hit_ids == k).sum() > 200 for k in range(3)) and (hit_ids >= 3).sum() > 50
+    p = api.make_params(96, 64, 16, max_depth=12, seed=3)
+    img, s1 = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+
+
 def _scaled_world(api, name, k, aspect):
     """The factory scene `name` with every length multiplied by k (centres, motion, radii, camera, lens), as a
     caller-built scene.  Directions, colours and texture frequencies-per-length (freq / k) follow."""

@@ -7,7 +7,7 @@ ctx = api.Context(0)
 w = api.World("FinalStatic", seed=1, aspect=1.5)
 ctx.upload(w.scene)
 acc = torch.zeros(800, 1200, 3, dtype=torch.float32, device="cuda")
-for spp in [125, 250, 500, 1000, 2000]:
+for spp in [int(x) for x in os.environ.get('SPPS', '125,250,500,1000,2000').split(',')]:
     p = api.make_params(1200, 800, spp, seed=w.render_seed, max_depth=int(os.environ.get("MAXD", "100")))
     st = ctx.render_accum_device(w.camera, p, acc.data_ptr())
     st = ctx.render_accum_device(w.camera, p, acc.data_ptr())
