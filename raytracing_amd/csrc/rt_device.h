@@ -32,6 +32,10 @@ constexpr int kChunk = 16;          // scan lists are padded to a multiple of th
 #define RT_TAILCOND __builtin_expect(__builtin_amdgcn_ballot_w64(any >= 0) != 0, 0)
 #endif
 constexpr int kGroup = RT_GROUP;    // spheres per lazy-root group of the scan (divides kChunk)
+#ifndef RT_SPARSE_RAYS
+#define RT_SPARSE_RAYS 16
+#endif
+constexpr int kSparseRays = RT_SPARSE_RAYS;
 constexpr int kLevels = 5;          // bound levels: groups (4 spheres), then 16, 64, 256, 1024 spheres
 // number of nodes of bound level L for a list of n_chunks chunks, and the level's offset in the bound array
 __host__ __device__ inline int bound_level_count(int n_chunks, int L) {
@@ -85,6 +89,9 @@ struct ScanLists {
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
     float cmax;             // max |c| over the static list, in the scan frame
     int32_t stat_levels, mov_levels;  // bit L >= 1 set: bound level L is worth testing for this list (upload decides)
+    // the same for a wave with at most kSparseRays live rays (the end of a launch, when the last long paths are traced
+    // a pass at a time): few rays meet few nodes, so every level with at least two nodes is worth its tests
+    int32_t stat_levels_sparse, mov_levels_sparse;
 };
 // A "big" sphere as the per-ray f64 test reads it: the exact f64 images of the caller's fp32 numbers (r2 = r * r is
 // exact in f64), fetched with ONE scalar load per sphere (wave-uniform index) and used straight from SGPRs.
