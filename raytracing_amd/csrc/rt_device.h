@@ -97,7 +97,7 @@ struct ScanLists {
 // exact in f64), fetched with ONE scalar load per sphere (wave-uniform index) and used straight from SGPRs.
 struct BigSphere {
     double cx, cy, cz, r2;
-    double dcx, dcy, dcz, inv_r;  // inv_r: 1/r rounded to fp32, as in DevScene::inv_rad
+    double dcx, dcy, dcz, inv_r;  // inv_r: 1/r rounded to fp32, as in DevScene::rec_a
 };
 static_assert(sizeof(BigSphere) == 64, "BigSphere = one s_load_dwordx16");
 // What scatter reads for the sphere a path hit, flattened per sphere (48 B, three 16-byte loads in ONE round trip
