@@ -193,6 +193,61 @@ def test_textures_all_noise_scenes(ctx, api):
         ctx.texture_batch(9999, pts)
 
 
+def test_six_noise_textures_in_one_scene(ctx, api, orc):
+    """The library's limit: six (noise table, noise kind) pairs in one scene (54 KiB of fused tables in LDS next to
+    ONE tile buffer per wave: the second would not fit 64 KiB).  A wave's hits then carry several different noise
+    textures at once, which the factory scenes (one noise texture each) never do: noise_pair loops over the distinct
+    textures of the wave.  Every texture against the oracle point by point, then a small render at path level."""
+    srcs = ["PerlinTurbulence", "ValueMarbled", "PerlinNoisePink", "ValueNoise2", "PerlinMarbled", "ValueTurbulence"]
+    worlds = [api.World(n, seed=1) for n in srcs]
+    # tables of the value-noise worlds: they carry `randoms` as well as `perms`, so both noise kinds are non-trivial on them
+    tables = [api.NoiseTable.from_buffer_copy(worlds[k].scene.noise_tables[0]) for k in (1, 3, 5)]
+    assert all(np.abs(np.array(t.randoms[:])).max() > 0 for t in tables)
+    texs = []
+    for k, w in enumerate(worlds):
+        s = w.scene
+        t = next(api.Texture.from_buffer_copy(s.textures[i]) for i in range(s.n_textures)
+                 if s.textures[i].kind in (api.RT_TEX_VALUE_NOISE, api.RT_TEX_PERLIN_NOISE))
+        t.table_id = k % 3
+        texs.append(t)
+    pairs = {(t.table_id, t.kind) for t in texs}
+    assert len(pairs) == 6, pairs
+    c0 = np.array([(0, -1000, 0)] + [(3.2 * (k - 2.5), 1.0, 0.8 * (k % 2)) for k in range(6)], np.float32)
+    rad = np.array([1000] + [1.0] * 6, np.float32)
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, k) for k in range(6)]
+    mid = np.array([0, 0, 1, 2, 3, 4, 5], np.uint32)
+    fs = api.FlatScene(c0, rad, mid, mats, texs, noise_tables=tables)
+    ctx.upload(fs.scene)
+    pts = golden("textures.npz")["points"]
+    near = np.abs(pts).max(1) <= 12.5
+    for k in range(6):
+        got = ctx.texture_batch(k, pts[near])
+        exp = orc.texture_batch(fs.scene, k, pts[near])
+        err = float(np.abs(got - exp).max())
+        print(srcs[k], "table", texs[k].table_id, "max err", err, "value range", float(exp.min()), float(exp.max()))
+        assert err < 2e-5 and exp.max() - exp.min() > 0.2, (srcs[k], err)
+    cam = api.camera_build((0, 3, 14), (0, 1, 0), vfov_degrees=40.0, aspect_ratio=96 / 64)
+    p = api.make_params(96, 64, 32, max_depth=8, seed=9)
+    img, st = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    r = rmse_gamma(img, ref)
+    print("render rmse(gamma)", r, "rays", int(st.rays_traced), rays_ref)
+    assert r < 0.01 and abs(int(st.rays_traced) - rays_ref) < 0.005 * rays_ref
+    # one more pair than fits
+    t7 = api.Texture.from_buffer_copy(texs[0])
+    t7.table_id = 3
+    t7.kind = api.RT_TEX_VALUE_NOISE
+    tables4 = tables + [api.NoiseTable.from_buffer_copy(worlds[3].scene.noise_tables[0])]
+    mats7 = mats + [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 6)]
+    c7 = np.concatenate([c0, np.array([[0, 3, 0]], np.float32)])
+    fs7 = api.FlatScene(c7, np.append(rad, 1.0).astype(np.float32), np.append(mid, 6).astype(np.uint32), mats7, texs + [t7],
+                        noise_tables=tables4)
+    with pytest.raises(api.RtError) as e:
+        ctx.upload(fs7.scene)
+    assert e.value.code == api.RT_ERR_SCENE_TOO_LARGE
+    ctx.upload(fs.scene)  # the context still works after the refusal
+
+
 def test_render_path_level_parity_small(ctx, api):
     """Same counter RNG + same maps => the GPU image follows the oracle's sample for sample; only rays whose
     fp32 decisions flip differ. 100x56 @ 16 spp against the committed oracle image."""
