@@ -383,6 +383,23 @@ def test_work_unit_size_does_not_change_the_image(ctx, api):
             assert st.rays_traced == base[1], f"unit={unit} bufs={bufs}"
 
 
+@pytest.mark.parametrize("W,H,spp", [(2, 2, 64), (3, 5, 33), (9, 7, 16), (65, 2, 9), (8, 8, 1)])
+def test_tiny_and_ragged_images(ctx, api, orc, W, H, spp):
+    """Images smaller than one 8x8 tile, with ragged tiles on both edges, one pixel row pair, odd sample counts: the
+    item indexing of a ragged tile (the division path of the refill), the work-unit arithmetic and the flush of a
+    partial tile, against the oracle at path level."""
+    w = api.World("FinalStatic", seed=1, aspect=W / H)
+    ctx.upload(w.scene)
+    p = api.make_params(W, H, spp, max_depth=10, seed=w.render_seed)
+    img, st = ctx.render(w.camera, p)
+    ref, _, rays_ref = orc.render(w.scene, w.camera, p, mode=orc.MODE_COUNTER, n_threads=2)
+    assert img.shape == (H, W, 3) and st.samples == W * H * spp
+    assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
+    # a handful of paths: every one follows the oracle's unless a ray lands within rounding of a decision
+    assert np.median(np.abs(img - ref)) < 1e-5 and rmse_gamma(img, ref) < 0.05
+    assert abs(int(st.rays_traced) - rays_ref) <= max(2, 0.02 * rays_ref)
+
+
 def test_multi_launch_render_matches_partition(ctx, api):
     """A render of more than 2^31 samples is split into several kernel launches (each with its own unit queue).
     2048 x 2048 @ 520 spp = 2.18e9 samples -> 2 launches; it must equal the two halves rendered separately with
