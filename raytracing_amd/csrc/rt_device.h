@@ -88,6 +88,7 @@ struct ScanLists {
     int32_t ns_pad, nm_pad;
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
     float cmax;             // max |c| over the static list, in the scan frame
+    int32_t mov_axes;       // bit k set: some moving sphere has dc[k] != 0 (terms_moving skips the other axes)
     int32_t stat_levels, mov_levels;  // bit L >= 1 set: bound level L is worth testing for this list (upload decides)
     // the same for a wave with at most kSparseRays live rays (the end of a launch, when the last long paths are traced
     // a pass at a time): few rays meet few nodes, so every level with at least two nodes is worth its tests
@@ -316,10 +317,19 @@ __device__ __forceinline__ void terms_static_direct(v4f s, float nr2, const Pair
     q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{nr2, nr2})));
 }
 // moving sphere a = {c0, -r^2}, m = {dc, 0}: center(time) = c0 + time*dc (shape.rs:96-98)
+// kAxes: bit k set when SOME moving sphere of the scene may move along axis k.  An axis no sphere moves along has
+// dc = 0 for every sphere and time * 0 + x = x exactly, so its fma is left out: the scan is instantiated for "any
+// axes" (7) and for motion along one axis only (1, 2, 4: the reference's motion-blur scene bounces its spheres along y,
+// config.rs:170-176; 12 packed ops per test instead of 14) and upload tells which one a scene may use
+// (ScanLists::mov_axes).
+template <int kAxes = 7>
 __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b, f2& q) {
+    constexpr int axes = kAxes;
     const f2 h = splat2(0.5f);
-    const f2 ocx = fma2(r.time, f2{m.x, m.x}, fma2(r.m2ox, h, splat2(a.x))), ocy = fma2(r.time, f2{m.y, m.y}, fma2(r.m2oy, h, splat2(a.y))),
-             ocz = fma2(r.time, f2{m.z, m.z}, fma2(r.m2oz, h, splat2(a.z)));
+    f2 ocx = fma2(r.m2ox, h, splat2(a.x)), ocy = fma2(r.m2oy, h, splat2(a.y)), ocz = fma2(r.m2oz, h, splat2(a.z));
+    if constexpr ((axes & 1) != 0) ocx = fma2(r.time, f2{m.x, m.x}, ocx);
+    if constexpr ((axes & 2) != 0) ocy = fma2(r.time, f2{m.y, m.y}, ocy);
+    if constexpr ((axes & 4) != 0) ocz = fma2(r.time, f2{m.z, m.z}, ocz);
     b = fma2(ocz, r.dz, fma2(ocy, r.dy, ocx * r.dx));
     q = fma2(ocz, ocz, fma2(ocy, ocy, fma2(ocx, ocx, f2{a.w, a.w})));
 }
@@ -498,23 +508,32 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
     const cv4p ma = as_scalar(S.mov_a), mb = as_scalar(S.mov_b);
     const bool cull_moving = S.nm_pad > 0 && __builtin_amdgcn_ballot_w64(!(r.time.x >= 0.0f && r.time.x <= 1.0f) ||
                                                                         !(r.time.y >= 0.0f && r.time.y <= 1.0f)) == 0ull;
-    walk(as_scalar(S.mov_bound), S.nm_pad / kChunk, S.mov_levels, cull_moving, [&](int g) {
-        const int base = g * kGroup;
-        f2 b[kGroup], q[kGroup], disc[kGroup];
-        int any = (int)0x80000000;
+    auto moving_members = [&](auto axes_tag) {
+        constexpr int kAxes = decltype(axes_tag)::value;
+        walk(as_scalar(S.mov_bound), S.nm_pad / kChunk, S.mov_levels, cull_moving, [&](int g) {
+            const int base = g * kGroup;
+            f2 b[kGroup], q[kGroup], disc[kGroup];
+            int any = (int)0x80000000;
 #pragma unroll
-        for (int k = 0; k < kGroup; ++k) {
-            terms_moving(ma[base + k], mb[base + k], r, b[k], q[k]);
-            disc[k] = fma2(b[k], b[k], -q[k]);
-            any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
-        }
-        RT_STAT(0, 1);
-        if (RT_TAILCOND) {
-            RT_STAT(1, 1);
-            roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + base, fl, best_a,
-                                   best_b, idx_a, idx_b, dbg);
-        }
-    });
+            for (int k = 0; k < kGroup; ++k) {
+                terms_moving<kAxes>(ma[base + k], mb[base + k], r, b[k], q[k]);
+                disc[k] = fma2(b[k], b[k], -q[k]);
+                any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
+            }
+            RT_STAT(0, 1);
+            if (RT_TAILCOND) {
+                RT_STAT(1, 1);
+                roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + base, fl, best_a,
+                                       best_b, idx_a, idx_b, dbg);
+            }
+        });
+    };
+    switch (S.mov_axes) {  // wave-uniform; motion along ONE axis gets its own instantiation, anything else the general one
+        case 1: moving_members(std::integral_constant<int, 1>{}); break;
+        case 2: moving_members(std::integral_constant<int, 2>{}); break;
+        case 4: moving_members(std::integral_constant<int, 4>{}); break;
+        default: moving_members(std::integral_constant<int, 7>{}); break;
+    }
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg[i], (unsigned long long)dbg[i]);

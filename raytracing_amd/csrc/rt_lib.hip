@@ -277,7 +277,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; { const bool sparse = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays; L.stat_levels = sparse ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels; L.mov_levels = sparse ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels; } L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; { const bool sparse = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays; L.stat_levels = sparse ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels; L.mov_levels = sparse ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels; } L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b; L.mov_axes = K->S.lists.mov_axes;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 RT_MARK("scan");
                 scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
@@ -931,6 +931,8 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     D.lists.ox = org[0]; D.lists.oy = org[1]; D.lists.oz = org[2];
     D.lists.cmax = (float)(cmax * (1.0 + 1e-6));
     D.lists.stat_levels = stat_levels; D.lists.mov_levels = mov_levels;
+    D.lists.mov_axes = 0;
+    for (const float4& v : mov_b) D.lists.mov_axes |= (v.x != 0.0f ? 1 : 0) | (v.y != 0.0f ? 2 : 0) | (v.z != 0.0f ? 4 : 0);
     auto sparse_levels = [](size_t n_spheres) {
         int32_t m = 0;
         for (int L = 1; L < kLevels; ++L)

@@ -433,6 +433,38 @@ def _random_flat_scene(api, n, seed, moving_every=0):
     return api.FlatScene(c0, rad, mid, mats, texs, dc=dc)
 
 
+@pytest.mark.parametrize("axes", [(1, 0, 0), (0, 0, 1), (1, 1, 0), (1, 1, 1)])
+def test_motion_along_other_axes(ctx, api, orc, axes):
+    """The reference's motion-blur scene moves its spheres along y only, and so do the scenes above.  The scan has one
+    instantiation per single axis of motion (terms_moving leaves out the axes nothing moves along) and a general one:
+    x only, z only, two axes and all three against the oracle, ray batches with times over the whole shutter."""
+    rng = np.random.default_rng(sum(a << i for i, a in enumerate(axes)))
+    n = 600
+    c0 = np.empty((n, 3), np.float32)
+    c0[:, 0] = rng.uniform(-12, 12, n); c0[:, 1] = rng.uniform(0.3, 4, n); c0[:, 2] = rng.uniform(-12, 12, n)
+    rad = rng.uniform(0.2, 0.45, n).astype(np.float32)
+    dc = (rng.uniform(-0.6, 0.6, (n, 3)) * np.array(axes)).astype(np.float32)
+    dc[::3] = 0  # a third stays put (the static list)
+    c0[0] = (0, -1000, 0); rad[0] = 1000; dc[0] = 0
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_METAL, (0.8, 0.8, 0.6), 0.1, 0, -1)]
+    fs = api.FlatScene(c0, rad, (np.arange(n) % 2).astype(np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))], dc=dc)
+    ctx.upload(fs.scene)
+    cam = api.camera_build((16, 5, 12), (0, 1.5, 0), vfov_degrees=50.0, aspect_ratio=1.5, aperture=0.05, focus_dist=18.0,
+                           shutter=(0.0, 1.0))
+    m = 32768
+    rays = ctx.camera_rays(cam, rng.random((m, 2), dtype=np.float32), rng.random((m, 4), dtype=np.float32))
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(fs.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
+    moving_hit = (exp["hit"] == 1) & (np.abs(dc[np.maximum(exp["sphere_id"], 0)]).sum(1) > 0)
+    print(axes, st, "hits on moving spheres", int(moving_hit.sum()))
+    assert moving_hit.sum() > 2000
+    p = api.make_params(96, 64, 16, max_depth=10, seed=4)
+    img, s1 = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+
+
 def test_empty_world_is_all_sky(ctx, api, orc):
     """HitList with no objects (hit.rs:100-110 returns None): every ray misses, every sample is the sky gradient
     (main.rs:133-138); one ray per sample."""

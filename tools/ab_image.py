@@ -21,7 +21,7 @@ else:
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     from raytracing_amd import api
     ctx = api.Context(0)
-    w = api.World("FinalStatic", seed=1, aspect=100 / 56)
+    w = api.World(os.environ.get("SCENE", "FinalStatic"), seed=1, aspect=100 / 56)
     ctx.upload(w.scene)
     for depth in (1, 2, 3, 50):
         p = api.make_params(100, 56, 16, seed=w.render_seed, max_depth=depth)
