@@ -319,9 +319,11 @@ __device__ __forceinline__ void terms_static_direct(v4f s, float nr2, const Pair
 // moving sphere a = {c0, -r^2}, m = {dc, 0}: center(time) = c0 + time*dc (shape.rs:96-98)
 // kAxes: bit k set when SOME moving sphere of the scene may move along axis k.  An axis no sphere moves along has
 // dc = 0 for every sphere and time * 0 + x = x exactly, so its fma is left out: the scan is instantiated for "any
-// axes" (7) and for motion along one axis only (1, 2, 4: the reference's motion-blur scene bounces its spheres along y,
-// config.rs:170-176; 12 packed ops per test instead of 14) and upload tells which one a scene may use
-// (ScanLists::mov_axes).
+// axes" (7) and for "y only" (2: the reference's motion-blur scene bounces its spheres along y, config.rs:170-176;
+// 12 packed ops per test instead of 14) and upload tells which one a scene may use (ScanLists::mov_axes).  One
+// instantiation per single axis measured 1 % faster still on that scene but 2-3 % slower on the scenes that never
+// run this code (four copies of the moving walk instead of two: instruction-cache footprint), so x-only and z-only
+// motion take the general form.
 template <int kAxes = 7>
 __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b, f2& q) {
     constexpr int axes = kAxes;
@@ -528,12 +530,8 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             }
         });
     };
-    switch (S.mov_axes) {  // wave-uniform; motion along ONE axis gets its own instantiation, anything else the general one
-        case 1: moving_members(std::integral_constant<int, 1>{}); break;
-        case 2: moving_members(std::integral_constant<int, 2>{}); break;
-        case 4: moving_members(std::integral_constant<int, 4>{}); break;
-        default: moving_members(std::integral_constant<int, 7>{}); break;
-    }
+    if (S.mov_axes == 2) moving_members(std::integral_constant<int, 2>{});  // wave-uniform
+    else moving_members(std::integral_constant<int, 7>{});
 #ifdef RT_STATS
     if ((threadIdx.x & 63) == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_dbg[i], (unsigned long long)dbg[i]);

@@ -435,8 +435,8 @@ def _random_flat_scene(api, n, seed, moving_every=0):
 
 @pytest.mark.parametrize("axes", [(1, 0, 0), (0, 0, 1), (1, 1, 0), (1, 1, 1)])
 def test_motion_along_other_axes(ctx, api, orc, axes):
-    """The reference's motion-blur scene moves its spheres along y only, and so do the scenes above.  The scan has one
-    instantiation per single axis of motion (terms_moving leaves out the axes nothing moves along) and a general one:
+    """The reference's motion-blur scene moves its spheres along y only, and so do the scenes above: they run the
+    scan's "y only" instantiation (terms_moving leaves out the axes nothing moves along).  The general one: motion along
     x only, z only, two axes and all three against the oracle, ray batches with times over the whole shutter."""
     rng = np.random.default_rng(sum(a << i for i, a in enumerate(axes)))
     n = 600
