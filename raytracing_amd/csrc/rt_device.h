@@ -321,9 +321,9 @@ __device__ __forceinline__ void terms_static_direct(v4f s, float nr2, const Pair
 // dc = 0 for every sphere and time * 0 + x = x exactly, so its fma is left out: the scan is instantiated for "any
 // axes" (7) and for "y only" (2: the reference's motion-blur scene bounces its spheres along y, config.rs:170-176;
 // 12 packed ops per test instead of 14) and upload tells which one a scene may use (ScanLists::mov_axes).  One
-// instantiation per single axis measured 1 % faster still on that scene but 2-3 % slower on the scenes that never
-// run this code (four copies of the moving walk instead of two: instruction-cache footprint), so x-only and z-only
-// motion take the general form.
+// instantiation per single axis measured 1 % faster still on that scene but 2-3 % slower on the noise scenes, which
+// never run this code (a side effect of the larger kernel on the layout of the rest; not instruction-cache misses:
+// SQC_ICACHE_MISSES is 5e3 per 3e10 requests either way), so x-only and z-only motion take the general form.
 template <int kAxes = 7>
 __device__ __forceinline__ void terms_moving(v4f a, v4f m, const Pair& r, f2& b, f2& q) {
     constexpr int axes = kAxes;
