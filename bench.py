@@ -60,14 +60,16 @@ def scene_model(api, world):
             "flops_per_ray": FLOPS_STATIC * n_static + FLOPS_MOVING * n_moving, "flops_per_noise_hit": tex_flops}
 
 
-def roofline_of(model, rays, samples, kernel_ms, launches):
+def roofline_of(model, rays, samples, kernel_ms, launches, layout):
     """fp32 VALU roofline of the render kernel: algorithmic flops = sphere tests for every ray segment + (noise
     scenes) the texture arithmetic of every hit (hits = rays - samples: each path ends with exactly one miss)."""
     flops = rays * model["flops_per_ray"] + max(rays - samples, 0) * model["flops_per_noise_hit"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12
-    # template arguments as rocprofv3 prints them: <noise textures compiled in, two LDS tile buffers per wave>; the second
-    # is true for every scene with fewer than five fused noise tables, i.e. for all of BASELINE's
-    return {"bound": "valu", "kernel": "render_kernel<%s, true>" % ("true" if model["flops_per_noise_hit"] else "false"),
+    # template arguments as rocprofv3 prints them: <noise textures compiled in, two LDS tile buffers per wave, planar
+    # scan list>, from the layout the library chose at upload (rt_debug_scan_layout)
+    b = lambda v: "true" if v else "false"
+    kernel = "render_kernel<%s, %s, %s>" % (b(layout["noise"]), b(layout["tile_buffers"] == 2), b(layout["planar_slots"] > 0))
+    return {"bound": "valu", "kernel": kernel,
             "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_VALU_PEAK_TFLOPS, "flops_per_ray": model["flops_per_ray"],
             "flops_per_noise_hit": model["flops_per_noise_hit"],
@@ -199,7 +201,7 @@ def main():
 
     if rank == 0:
         value = samples_per_step * args.steps / dt
-        roof = roofline_of(model, rays, samples_rank, kernel_ms, launches)  # this rank's kernel
+        roof = roofline_of(model, rays, samples_rank, kernel_ms, launches, ctx.debug_scan_layout())  # this rank's kernel
         traffic = measured_traffic(args.scene, args.width, args.height, count)
         roof["traffic"] = traffic  # HBM bytes per launch, PMC passes of THIS workload (profiles/), else null
         roof["traffic_frac_of_hbm_peak"] = (traffic / (roof["kernel_ms_per_launch"] * 1e-3) / 8e12) if traffic else None
@@ -271,7 +273,8 @@ def extra_configs(api, torch, ctx, dev, runs=3):
         st = sorted(sts, key=lambda s: s.kernel_ms)[len(sts) // 2]  # median run
         finite = bool(torch.isfinite(acc).all().item())
         del acc
-        roof = roofline_of(model, int(st.rays_traced), int(st.samples), float(st.kernel_ms), int(st.n_launches))
+        roof = roofline_of(model, int(st.rays_traced), int(st.samples), float(st.kernel_ms), int(st.n_launches),
+                           ctx.debug_scan_layout())
         roof["traffic"] = measured_traffic(scene, W, H, spp)
         res.append({
             "config": tag, "scene": scene, "width": W, "height": H, "spp": spp, "spp_offset": off,

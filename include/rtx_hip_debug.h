@@ -19,10 +19,21 @@ int rt_debug_set_work_units(rt_ctx* ctx, uint32_t unit_a, uint32_t unit_b, int32
  * along a Morton curve (A/B switch for the lazy root extraction; results are identical). */
 int rt_debug_set_scan_order(rt_ctx* ctx, int world_order);
 
+/* on = 0: the next rt_upload_scene keeps every static small sphere in the general scan list instead of moving those whose
+ * centres share one coordinate into the planar list (cheaper tests); on != 0 restores the default.  Results are
+ * identical. */
+int rt_debug_set_planar_list(rt_ctx* ctx, int on);
+
 /* n = 1 or 2: the next rt_upload_scene gives every wave that many tile buffers in LDS (2: the in-flight paths of a
  * finished work unit keep adding into their tile's LDS sums; 1: they add straight into the global accumulators) when
  * that many fit; 0 restores the choice by LDS room and occupancy.  Results are identical. */
 int rt_debug_set_tile_buffers(rt_ctx* ctx, int n);
+
+/* How the last rt_upload_scene laid the world out for the scan, for tests and for bench.py's kernel name:
+ * out = {big spheres, general static slots, planar slots, moving slots (each padded to whole chunks of 8),
+ *        planar axis (0/1/2, -1 without a planar list), moving-list axis count (7 general / 2 y-only / 0 none),
+ *        tile buffers per wave, noise variant (0/1)}. */
+int rt_debug_scan_layout(rt_ctx* ctx, int32_t out[8]);
 
 #ifdef __cplusplus
 }

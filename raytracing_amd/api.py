@@ -115,7 +115,8 @@ ABI_SYMBOLS = [
     "rt_multi_upload_scene", "rt_multi_render", "rth_world_create", "rth_world_destroy", "rth_world_scene", "rth_world_camera",
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
-    "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers",
+    "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers", "rt_debug_set_planar_list",
+    "rt_debug_scan_layout",
 ]
 
 _lib = None
@@ -157,6 +158,9 @@ def load() -> C.CDLL:
     lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
     lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
     lib.rt_debug_set_tile_buffers.argtypes = [vp, C.c_int]
+    if hasattr(lib, "rt_debug_set_planar_list"):  # (absent from older builds that tools/ab*.sh compare against)
+        lib.rt_debug_set_planar_list.argtypes = [vp, C.c_int]
+        lib.rt_debug_scan_layout.argtypes = [vp, C.POINTER(C.c_int32 * 8)]
     lib.rt_intersect_batch.argtypes = [vp, vp, C.c_uint32, C.c_float, vp]
     lib.rt_scatter_batch.argtypes = [vp, vp, vp, vp, C.c_uint32, vp]
     lib.rt_texture_batch.argtypes = [vp, C.c_int32, vp, C.c_uint32, vp]
@@ -405,6 +409,18 @@ class Context:
     def debug_set_work_units(self, unit_a: int = 0, unit_b: int = 0, tail_span: int = -1):
         """include/rtx_hip_debug.h: force the work-unit schedule (0, 0, -1 = defaults)."""
         self._check(self.lib.rt_debug_set_work_units(self._h, unit_a, unit_b, tail_span))
+
+    def debug_set_planar_list(self, on: bool = True):
+        """include/rtx_hip_debug.h: static spheres with a shared centre coordinate in their own scan list (default) or
+        in the general one, from the next upload on."""
+        self._check(self.lib.rt_debug_set_planar_list(self._h, 1 if on else 0))
+
+    def debug_scan_layout(self) -> dict:
+        """include/rtx_hip_debug.h: how the last upload laid the world out for the scan."""
+        out = (C.c_int32 * 8)()
+        self._check(self.lib.rt_debug_scan_layout(self._h, C.byref(out)))
+        keys = ("n_big", "static_slots", "planar_slots", "moving_slots", "planar_axis", "moving_axes", "tile_buffers", "noise")
+        return dict(zip(keys, (int(v) for v in out)))
 
     def debug_set_tile_buffers(self, n: int = 0):
         """include/rtx_hip_debug.h: LDS tile buffers per wave from the next upload on (0 = chosen by the library)."""

@@ -84,6 +84,18 @@ struct ScanLists {
     // bounding spheres {bx, by, bz, |b|^2 - R^2} (w = +inf: nothing inside), kLevels levels one after another:
     // level 0 = every group of kGroup spheres, level L >= 1 = every run of 4^(L-1) chunks (16 * 4^(L-1) spheres)
     const float4* stat_bound;
+    // The PLANAR static list: static small spheres whose centres share one coordinate exactly (objects of one size
+    // resting on a floor: the reference's final scenes), laid out like the static list.  The shared coordinate's term
+    // drops out of every test as a per-ray constant (Pair::nod_p, qb_p): 6 packed ops per member instead of 8, 10 VALU
+    // per bound instead of 12.  Bounds as for the static list (their shared coordinate is plan_val too).  Scan slots
+    // [ns_pad, ns_pad + np_pad).
+    const float4* plan;
+    const float* plan_nr2;
+    const float4* plan_bound;
+    int32_t np_pad;
+    int32_t plan_axis;      // which axis the shared coordinate is on: 0, 1, 2
+    float plan_val;         // the shared coordinate, in the scan frame
+    int32_t plan_levels, plan_levels_sparse;
     const float4* mov_a;    // nm_pad x {c0x, c0y, c0z, -r^2}; pads -r^2 = +inf
     const float4* mov_b;    // nm_pad x {dcx, dcy, dcz, 0}
     const float4* mov_bound;  // the same levels for the moving list, over the whole motion for time in [0, 1]
@@ -277,6 +289,9 @@ struct Pair {
     // per-ray terms of the expanded static test
     f2 nod;               // -(o' . d^)
     f2 qb;                // |o'|^2 - E, E = kExpandErr (|o'| + cmax)^2: the error bound of the expanded disc
+    // the planar list's shared coordinate folded into the per-ray constants: nod_p = nod + plan_val * d_k,
+    // qb_p = qb + plan_val * (-2 o'_k)
+    f2 nod_p, qb_p;
 };
 
 // STATIC spheres, every sphere: the EXPANDED form, 8 packed ops for both rays (the direct form below needs 10):
@@ -310,6 +325,32 @@ __device__ __forceinline__ int bound_reject_bits(v4f s, const Pair& r) {
     const int ux = (__float_as_int(b.x) & __float_as_int(nq.x)) | __float_as_int(disc.x);
     const int uy = (__float_as_int(b.y) & __float_as_int(nq.y)) | __float_as_int(disc.y);
     return ux & uy;  // sign set <=> neither ray of this lane can meet the bound
+}
+// The planar list's versions, kAxis = the shared coordinate's axis: its terms are in nod_p / qb_p and are left out.
+template <int kAxis>
+__device__ __forceinline__ void planar_b_q(v4f s, const Pair& r, f2 q0, f2& b, f2& q) {
+    b = r.nod_p;
+    q = q0;
+    if constexpr (kAxis != 0) { b = fma2(f2{s.x, s.x}, r.dx, b); q = fma2(f2{s.x, s.x}, r.m2ox, q); }
+    if constexpr (kAxis != 1) { b = fma2(f2{s.y, s.y}, r.dy, b); q = fma2(f2{s.y, s.y}, r.m2oy, q); }
+    if constexpr (kAxis != 2) { b = fma2(f2{s.z, s.z}, r.dz, b); q = fma2(f2{s.z, s.z}, r.m2oz, q); }
+}
+template <int kAxis>
+__device__ __forceinline__ f2 disc_planar_expanded(v4f s, const Pair& r) {
+    f2 b, q;
+    planar_b_q<kAxis>(s, r, s.w + r.qb_p, b, q);
+    return fma2(b, b, -q);
+}
+template <int kAxis>
+__device__ __forceinline__ int bound_reject_bits_planar(v4f s, const Pair& r) {
+    f2 b = r.nod_p, nq = -s.w - r.qb_p;  // -q is what the chain computes (negations are free source modifiers)
+    if constexpr (kAxis != 0) { b = fma2(f2{s.x, s.x}, r.dx, b); nq = fma2(f2{s.x, s.x}, -r.m2ox, nq); }
+    if constexpr (kAxis != 1) { b = fma2(f2{s.y, s.y}, r.dy, b); nq = fma2(f2{s.y, s.y}, -r.m2oy, nq); }
+    if constexpr (kAxis != 2) { b = fma2(f2{s.z, s.z}, r.dz, b); nq = fma2(f2{s.z, s.z}, -r.m2oz, nq); }
+    const f2 disc = fma2(b, b, nq);
+    const int ux = (__float_as_int(b.x) & __float_as_int(nq.x)) | __float_as_int(disc.x);
+    const int uy = (__float_as_int(b.y) & __float_as_int(nq.y)) | __float_as_int(disc.y);
+    return ux & uy;
 }
 // b and q of one sphere for both rays, DIRECT form.  static sphere: centre s.xyz, nr2 = -r^2
 __device__ __forceinline__ void terms_static_direct(v4f s, float nr2, const Pair& r, f2& b, f2& q) {
@@ -406,7 +447,7 @@ __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direc
 // (disc >= 0 <=> sign bit clear; one v_max3_i32 per sphere folds the 2*kGroup sign bits, one compare and one
 // wave-uniform branch per group decide).  Upload orders the lists along a Morton curve so the spheres of a group
 // are neighbours and the groups a wave's rays meet are few.
-template <bool kFloor>
+template <bool kFloor, bool kPlanar>
 __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, const Floor& fl, uint32_t& best_a,
                                              uint32_t& best_b, int& idx_a, int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -464,11 +505,43 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
     // (measured on configs[1]: 34 % of the group bounds pass; a wave's 128 rays leave from a few hit points in all
     // directions, so only distant groups are skipped).  One s_load_dwordx16 brings the bounds of a chunk's 4 groups.
     static_assert(kGroup == 4 && kChunk == 16, "one s_load_dwordx16 = the bounds of 4 groups = one chunk");
-    auto met = [&](v4f bound) {
+    auto met3 = [&](v4f bound) {
         RT_STAT(5, 1);
         return __builtin_amdgcn_ballot_w64(bound_reject_bits(bound, r) >= 0) != 0ull;
     };
-    auto chunk = [&](cv4p bd, int c, bool cull, auto&& members) {  // the 4 groups of chunk c
+    // the planar list (see ScanLists::plan), instantiated per axis of the shared coordinate
+    const cv4p pl = as_scalar(S.plan);
+    auto planar_walk = [&](auto axis_tag, auto&& walk_fn) {
+        constexpr int kAxis = decltype(axis_tag)::value;
+        auto metp = [&](v4f bound) {
+            RT_STAT(5, 1);
+            return __builtin_amdgcn_ballot_w64(bound_reject_bits_planar<kAxis>(bound, r) >= 0) != 0ull;
+        };
+        walk_fn(as_scalar(S.plan_bound), S.np_pad / kChunk, S.plan_levels, true, metp, [&](int g) {
+            const int base = g * kGroup;
+            v4f sp[kGroup];
+            f2 disc[kGroup];
+            int any = (int)0x80000000;
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) sp[k] = pl[base + k];
+#pragma unroll
+            for (int k = 0; k < kGroup; ++k) {
+                disc[k] = disc_planar_expanded<kAxis>(sp[k], r);
+                any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
+            }
+            RT_STAT(0, 1);
+            if (RT_TAILCOND) {
+                RT_STAT(1, 1);
+                const v4f nr2 = *(cv4p)(uintptr_t)(S.plan_nr2 + base);
+                roots_of_group<kFloor>(disc, [&](int k, f2& b, f2& d) {
+                    f2 q;
+                    terms_static_direct(sp[k], nr2[k], r, b, q);
+                    d = fma2(b, b, -q);
+                }, S.ns_pad + base, fl, best_a, best_b, idx_a, idx_b, dbg);
+            }
+        });
+    };
+    auto chunk = [&](cv4p bd, int c, bool cull, auto&& met, auto&& members) {  // the 4 groups of chunk c
         v4f bound[kChunk / kGroup];
 #pragma unroll
         for (int g = 0; g < kChunk / kGroup; ++g) bound[g] = bd[c * (kChunk / kGroup) + g];
@@ -476,9 +549,9 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
         for (int g = 0; g < kChunk / kGroup; ++g)
             if (!cull || met(bound[g])) { RT_STAT(6, 1); members(c * (kChunk / kGroup) + g); }
     };
-    auto walk = [&](cv4p bd, int n_chunks, int levels, bool cull, auto&& members) {
+    auto walk = [&](cv4p bd, int n_chunks, int levels, bool cull, auto&& met, auto&& members) {
         if (!cull || levels == 0) {  // small scenes: the group bounds only, no bookkeeping in the loop
-            for (int c = 0; c < n_chunks; ++c) chunk(bd, c, cull, members);
+            for (int c = 0; c < n_chunks; ++c) chunk(bd, c, cull, met, members);
             return;
         }
         int off[kLevels];
@@ -495,17 +568,22 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                 }
             }
             if (skipped) continue;
-            chunk(bd, c, true, members);
+            chunk(bd, c, true, met, members);
             ++c;
         }
     };
 #ifndef RT_NOSCAN
-    walk(as_scalar(S.stat_bound), S.ns_pad / kChunk, S.stat_levels, true, [&](int g) {
+    walk(as_scalar(S.stat_bound), S.ns_pad / kChunk, S.stat_levels, true, met3, [&](int g) {
         v4f sp[kGroup];
 #pragma unroll
         for (int k = 0; k < kGroup; ++k) sp[k] = st[g * kGroup + k];
         group(sp, g * kGroup);
     });
+    if (kPlanar && S.np_pad > 0) {  // wave-uniform
+        if (S.plan_axis == 0) planar_walk(std::integral_constant<int, 0>{}, walk);
+        else if (S.plan_axis == 1) planar_walk(std::integral_constant<int, 1>{}, walk);
+        else planar_walk(std::integral_constant<int, 2>{}, walk);
+    }
 #endif
     // The moving list: a bound covers its members' whole motion for time in [0, 1] (the segments c0 .. c0 + dc).  A
     // ray outside that time range (the fixed-batch entry point takes any) switches the culling off for its wave.
@@ -514,7 +592,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                                                                         !(r.time.y >= 0.0f && r.time.y <= 1.0f)) == 0ull;
     auto moving_members = [&](auto axes_tag) {
         constexpr int kAxes = decltype(axes_tag)::value;
-        walk(as_scalar(S.mov_bound), S.nm_pad / kChunk, S.mov_levels, cull_moving, [&](int g) {
+        walk(as_scalar(S.mov_bound), S.nm_pad / kChunk, S.mov_levels, cull_moving, met3, [&](int g) {
             const int base = g * kGroup;
             f2 b[kGroup], q[kGroup], disc[kGroup];
             int any = (int)0x80000000;
@@ -527,8 +605,8 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             RT_STAT(0, 1);
             if (RT_TAILCOND) {
                 RT_STAT(1, 1);
-                roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + base, fl, best_a,
-                                       best_b, idx_a, idx_b, dbg);
+                roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + S.np_pad + base, fl,
+                                       best_a, best_b, idx_a, idx_b, dbg);
             }
         });
     };
@@ -673,10 +751,11 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
 __device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
 __device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? h.front : 0x7FFFFFFF; }
 // the scan with or without the floor, chosen per wave
+template <bool kPlanar>
 __device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Pair& p, const Floor& fl, uint32_t& best_a,
                                                 uint32_t& best_b, int& slot_a, int& slot_b) {
-    if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull) scan_spheres<true>(L, p, fl, best_a, best_b, slot_a, slot_b);
-    else scan_spheres<false>(L, p, fl, best_a, best_b, slot_a, slot_b);
+    if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull) scan_spheres<true, kPlanar>(L, p, fl, best_a, best_b, slot_a, slot_b);
+    else scan_spheres<false, kPlanar>(L, p, fl, best_a, best_b, slot_a, slot_b);
 }
 
 // HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
@@ -689,6 +768,7 @@ struct Hit2 {
     uint32_t best_a, best_b;
     int slot_a, slot_b;
 };
+template <bool kPlanar>
 __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                               float t_min, Hit2& x) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -739,6 +819,12 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     const f2 oo = fma2(oz, oz, fma2(oy, oy, ox * ox));
     const f2 m = f2{fast_sqrt(oo.x), fast_sqrt(oo.y)} + L.cmax;
     p.qb = fma2(m * m, splat2(-kExpandErr), oo);
+    if (kPlanar) {  // the planar list's shared coordinate, folded (wave-uniform selects)
+        const int ax = L.plan_axis;
+        const f2 dk = ax == 0 ? p.dx : ax == 1 ? p.dy : p.dz, mk = ax == 0 ? p.m2ox : ax == 1 ? p.m2oy : p.m2oz;
+        p.nod_p = fma2(splat2(L.plan_val), dk, p.nod);
+        p.qb_p = fma2(splat2(L.plan_val), mk, p.qb);
+    }
     x.slot_a = x.slot_b = -1;
 }
 __device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
@@ -756,8 +842,8 @@ __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, c
     while (__ballot(do_a || do_b) != 0ull) {  // wave-uniform: every lane runs the packed scan together
         Hit2 x;
         HitRec na, nb;
-        closest_begin(S, ra, rb, do_a, do_b, t_min, x);
-        scan_with_floor(S.lists, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
+        closest_begin<true>(S, ra, rb, do_a, do_b, t_min, x);
+        scan_with_floor<true>(S.lists, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
         closest_end(S, ra, rb, do_a, do_b, t_min, x, na, nb);
         if (do_a) { ha = na; fl.lo_a = retry_key(na); fl.ls_a = retry_slot(na); do_a = na.sphere == kRetry; }
         if (do_b) { hb = nb; fl.lo_b = retry_key(nb); fl.ls_b = retry_slot(nb); do_b = nb.sphere == kRetry; }

@@ -92,8 +92,9 @@ constexpr uint32_t kOrphan = 0xFFFFFFFFu;         // PathState::acc_idx of a pat
 __host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (size_t)acc_bufs * kTileAcc * sizeof(unsigned long long) + 16; }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 3  // ~144 VGPRs, no scratch.  4 waves per SIMD (128 VGPRs) measure +2 % but spill 22 dwords per
-                           // lane, i.e. tens of GB of scratch writes per launch; 2 waves measure -1 %
+#define RT_WAVES_PER_EU 3  // 168 VGPRs.  Four waves per SIMD (128 VGPRs) spill ~60 dwords per lane and measure +1 %; a build
+                           // held to two (170 VGPRs, no spill at all) measures the same as three within 0.2 % on
+                           // configs[1] and Random and 1 % faster on PerlinNoise2: the VALU pipes are busy either way
 #endif
 // Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
 #ifdef RT_CENSUS
@@ -101,7 +102,7 @@ __host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (si
 #else
 #define RT_MARK(name)
 #endif
-template <bool kNoise, bool kTwoBufs>
+template <bool kNoise, bool kTwoBufs, bool kPlanar>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
     // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
     // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
@@ -273,14 +274,16 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             const Floor fl = {ps[0].alive ? retry_key(h[0]) : -1, ps[1].alive ? retry_key(h[1]) : -1,
                               retry_slot(h[0]), retry_slot(h[1])};
             RT_MARK("begin");
-            closest_begin(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
+            closest_begin<kPlanar>(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
             {
                 const ArgsPtr K = launder(K0);
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; { const bool sparse = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays; L.stat_levels = sparse ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels; L.mov_levels = sparse ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels; } L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b; L.mov_axes = K->S.lists.mov_axes;
+                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; const bool sparse_pass = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays; L.stat_levels = sparse_pass ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels; L.mov_levels = sparse_pass ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b; L.mov_axes = K->S.lists.mov_axes;
+                if (kPlanar) L.plan = K->S.lists.plan, L.plan_nr2 = K->S.lists.plan_nr2; L.plan_bound = K->S.lists.plan_bound; L.np_pad = K->S.lists.np_pad; L.plan_axis = K->S.lists.plan_axis;
+                L.plan_levels = sparse_pass ? K->S.lists.plan_levels_sparse : K->S.lists.plan_levels;
                 L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
                 RT_MARK("scan");
-                scan_with_floor(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
+                scan_with_floor<kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
             }
             RT_MARK("end");
             closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
@@ -328,9 +331,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
 // the variant a scene runs: with or without the noise textures compiled in, two tile buffers per wave or one
 typedef void (*RenderKernel)(const RenderArgs);
-static RenderKernel render_variant(bool noise, bool two_bufs) {
-    return noise ? (two_bufs ? render_kernel<true, true> : render_kernel<true, false>)
-                 : (two_bufs ? render_kernel<false, true> : render_kernel<false, false>);
+template <bool kNoise, bool kTwoBufs>
+static RenderKernel render_variant2(bool planar) { return planar ? render_kernel<kNoise, kTwoBufs, true> : render_kernel<kNoise, kTwoBufs, false>; }
+static RenderKernel render_variant(bool noise, bool two_bufs, bool planar) {
+    return noise ? (two_bufs ? render_variant2<true, true>(planar) : render_variant2<true, false>(planar))
+                 : (two_bufs ? render_variant2<false, true>(planar) : render_variant2<false, false>(planar));
 }
 
 __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ out, size_t n,
@@ -499,6 +504,8 @@ struct rt_ctx {
     uint32_t dbg_unit_a = 0, dbg_unit_b = 0;
     int32_t dbg_tail_span = -1;
     bool dbg_world_order = false;
+    bool dbg_no_planar = false;
+    bool has_planar = false;  // the scene has a planar list: the render kernel variant with its walk
     int dbg_tile_bufs = 0;
 };
 
@@ -727,6 +734,44 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     const float org[3] = {(float)(0.5 * (lo3[0] + hi3[0])), (float)(0.5 * (lo3[1] + hi3[1])), (float)(0.5 * (lo3[2] + hi3[2]))};
     std::vector<float> stat_nr2;
     double cmax = 0.0;
+    // The planar list (ScanLists::plan): the largest set of static small spheres whose centres share one coordinate
+    // EXACTLY (compared in the scan frame, where the kernel multiplies them), when it has at least kPlanarMin members.
+    // Below that the separate walk costs more than the cheaper tests save (Random, 97 static spheres in y = 0.2:
+    // +1.2 % with the list; configs[1], 480: -8.3 %): the spheres left on the general list still cost a chunk.
+    constexpr size_t kPlanarMin = 160;
+    int plan_axis = 2;
+    float plan_val = 0.0f;
+    std::vector<char> is_planar(s->n_spheres, 0);
+    if (!c->dbg_no_planar) {
+        size_t best = 0;
+        for (int a = 0; a < 3; ++a) {
+            std::vector<float> vals;
+            for (uint32_t i = 0; i < s->n_spheres; ++i) {
+                if (is_big[i] || s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) continue;
+                const float c3[3] = {s->c0x[i], s->c0y[i], s->c0z[i]};
+                vals.push_back((float)((double)c3[a] - org[a]));
+            }
+            std::sort(vals.begin(), vals.end());
+            for (size_t i = 0; i < vals.size();) {
+                size_t j = i;
+                while (j < vals.size() && vals[j] == vals[i]) ++j;
+                if (j - i > best) { best = j - i; plan_axis = a; plan_val = vals[i]; }
+                i = j;
+            }
+        }
+        if (best >= kPlanarMin) {
+            for (uint32_t i = 0; i < s->n_spheres; ++i) {
+                if (is_big[i] || s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) continue;
+                const float c3[3] = {s->c0x[i], s->c0y[i], s->c0z[i]};
+                is_planar[i] = (float)((double)c3[plan_axis] - org[plan_axis]) == plan_val;
+            }
+        } else {
+            plan_val = 0.0f;
+        }
+    }
+    std::vector<float4> plan;
+    std::vector<float> plan_nr2;
+    std::vector<int32_t> plan_id;
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const double r = s->radius[i];
         const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
@@ -740,9 +785,16 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         } else {
             // w = |c|^2 - r^2 from the ROUNDED centre the kernel multiplies with, in f64, rounded once
             const double fx = (float)cx, fy = (float)cy, fz = (float)cz;
-            stat.push_back(make_float4((float)cx, (float)cy, (float)cz, (float)(fx * fx + fy * fy + fz * fz - r * r)));
-            stat_nr2.push_back((float)-(r * r));
-            stat_id.push_back((int32_t)i);
+            const float w = (float)(fx * fx + fy * fy + fz * fz - r * r);
+            if (is_planar[i]) {
+                plan.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
+                plan_nr2.push_back((float)-(r * r));
+                plan_id.push_back((int32_t)i);
+            } else {
+                stat.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
+                stat_nr2.push_back((float)-(r * r));
+                stat_id.push_back((int32_t)i);
+            }
             cmax = std::max(cmax, std::sqrt(fx * fx + fy * fy + fz * fz));
         }
     }
@@ -791,6 +843,14 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             stat.swap(s2); stat_nr2.swap(r2); stat_id.swap(i2);
         }
         {
+            const std::vector<uint32_t> perm = morton_order(plan);
+            std::vector<float4> s2(plan.size());
+            std::vector<float> r2(plan.size());
+            std::vector<int32_t> i2(plan.size());
+            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = plan[perm[k]]; r2[k] = plan_nr2[perm[k]]; i2[k] = plan_id[perm[k]]; }
+            plan.swap(s2); plan_nr2.swap(r2); plan_id.swap(i2);
+        }
+        {
             const std::vector<uint32_t> perm = morton_order(mov_a);  // by the centre at time 0
             std::vector<float4> a2(mov_a.size()), b2(mov_a.size());
             std::vector<int32_t> i2(mov_a.size());
@@ -801,6 +861,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     // pads are never nominated: -r^2 = +inf makes disc = b^2 - inf negative whatever the ray is
     const float kPad = std::numeric_limits<float>::infinity();
     while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, kPad)); stat_nr2.push_back(kPad); stat_id.push_back(-1); }
+    while (plan.size() % kChunk) { plan.push_back(make_float4(0, 0, 0, kPad)); plan_nr2.push_back(kPad); plan_id.push_back(-1); }
     while (mov_a.size() % kChunk) {
         mov_a.push_back(make_float4(0, 0, 0, kPad));
         mov_b.push_back(make_float4(0, 0, 0, 0));
@@ -861,10 +922,16 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         }
         return out;
     };
-    int32_t stat_levels = 0, mov_levels = 0;
+    int32_t stat_levels = 0, mov_levels = 0, plan_levels = 0;
     const std::vector<float4> stat_bound = build_bounds(stat, nullptr, &stat_nr2, stat_id, &stat_levels);
+    std::vector<float4> plan_bound = build_bounds(plan, nullptr, &plan_nr2, plan_id, &plan_levels);
+    for (float4& b : plan_bound) {  // a bound's centre is the mean of its members': the shared coordinate again, to the bit
+        const float b3[3] = {b.x, b.y, b.z};
+        if (b.w != kPad && b3[plan_axis] != plan_val) return fail(c, RT_ERR_HIP, "internal: planar bound left its plane");
+    }
     const std::vector<float4> mov_bound = build_bounds(mov_a, &mov_b, nullptr, mov_id, &mov_levels);
-    std::vector<int32_t> scan_id(stat_id);
+    std::vector<int32_t> scan_id(stat_id);  // scan slots: static, planar, moving (the order the scan walks them)
+    scan_id.insert(scan_id.end(), plan_id.begin(), plan_id.end());
     scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
     const size_t lds_need = lds_scene_bytes((int)fused.size());
     if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
@@ -877,6 +944,9 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, stat_nr2.data(), stat_nr2.size(), &D.lists.stat_nr2));
     UP(dev_copy(c, stat_bound.data(), stat_bound.size(), &D.lists.stat_bound));
     UP(dev_copy(c, mov_bound.data(), mov_bound.size(), &D.lists.mov_bound));
+    UP(dev_copy(c, plan.data(), plan.size(), &D.lists.plan));
+    UP(dev_copy(c, plan_nr2.data(), plan_nr2.size(), &D.lists.plan_nr2));
+    UP(dev_copy(c, plan_bound.data(), plan_bound.size(), &D.lists.plan_bound));
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
@@ -939,6 +1009,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             if (bound_level_count((int)(n_spheres / kChunk), L) >= 2) m |= 1 << L;
         return m;
     };
+    D.lists.np_pad = (int32_t)plan.size();
+    c->has_planar = !plan.empty();
+    D.lists.plan_axis = plan_axis;
+    D.lists.plan_val = plan_val;
+    D.lists.plan_levels = plan_levels;
+    D.lists.plan_levels_sparse = plan_levels | sparse_levels(plan.size());
     D.lists.stat_levels_sparse = stat_levels | sparse_levels(stat.size());
     D.lists.mov_levels_sparse = mov_levels | sparse_levels(mov_a.size());
     D.lists.ns_pad = (int32_t)stat.size();
@@ -960,7 +1036,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     for (uint32_t bufs = 1; bufs <= 2; ++bufs) {
         const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(bufs);
         if (lds_bytes > 65536) continue;
-        RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2), kBlock, lds_bytes));
+        RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2, c->has_planar), kBlock, lds_bytes));
     }
     c->acc_bufs = (occ[2] >= occ[1] && occ[2] > 0) ? 2 : 1;
     if (c->dbg_tile_bufs && occ[c->dbg_tile_bufs] > 0) c->acc_bufs = (uint32_t)c->dbg_tile_bufs;  // rt_debug_set_tile_buffers
@@ -1047,7 +1123,7 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
         A.unit_counter = reinterpret_cast<unsigned int*>(counters + 1);
         RT_HIP(c, hipMemsetAsync(counters + 1, 0, sizeof(unsigned long long), c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
-        hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
+        hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2, c->has_planar), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
         done += spp_l;
         ++launches;
@@ -1136,6 +1212,20 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rg
 int rt_debug_set_work_units(rt_ctx* c, uint32_t unit_a, uint32_t unit_b, int32_t tail_span) {
     if (!c) return RT_ERR_BAD_ARG;
     c->dbg_unit_a = unit_a; c->dbg_unit_b = unit_b; c->dbg_tail_span = tail_span;
+    return RT_OK;
+}
+int rt_debug_set_planar_list(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_BAD_ARG;
+    c->dbg_no_planar = on == 0;
+    return RT_OK;
+}
+int rt_debug_scan_layout(rt_ctx* c, int32_t out[8]) {
+    if (!c || !out) return RT_ERR_BAD_ARG;
+    if (!c->has_scene) return fail(c, RT_ERR_NO_SCENE, "no scene uploaded");
+    const ScanLists& L = c->S.lists;
+    const int32_t v[8] = {c->S.n_big, L.ns_pad, L.np_pad, L.nm_pad, L.np_pad > 0 ? L.plan_axis : -1,
+                          L.nm_pad > 0 ? L.mov_axes : 0, (int32_t)c->acc_bufs, c->has_noise ? 1 : 0};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
     return RT_OK;
 }
 int rt_debug_set_tile_buffers(rt_ctx* c, int n) {

@@ -381,6 +381,20 @@ def test_work_unit_size_does_not_change_the_image(ctx, api):
         else:
             assert np.array_equal(img, base[0]), f"unit={unit} bufs={bufs}"
             assert st.rays_traced == base[1], f"unit={unit} bufs={bufs}"
+    # the scan-list layout is one more thing the image must not depend on: configs[1]'s scene with its grid of small
+    # spheres in the planar list (default) and in the general one
+    w = api.World("FinalStatic", seed=1, aspect=1.5)
+    p = api.make_params(150, 100, 24, seed=w.render_seed)
+    res = []
+    for planar in (True, False):
+        ctx.debug_set_planar_list(planar)
+        try:
+            ctx.upload(w.scene)
+            assert (ctx.debug_scan_layout()["planar_slots"] > 0) == planar
+            res.append(ctx.render(w.camera, p))
+        finally:
+            ctx.debug_set_planar_list(True)
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1].rays_traced == res[1][1].rays_traced
 
 
 @pytest.mark.parametrize("W,H,spp", [(2, 2, 64), (3, 5, 33), (9, 7, 16), (65, 2, 9), (8, 8, 1)])
@@ -463,6 +477,78 @@ def test_motion_along_other_axes(ctx, api, orc, axes):
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
     assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+
+
+@pytest.mark.parametrize("axis", [0, 1, 2])
+def test_planar_scan_list(ctx, api, orc, axis):
+    """Static small spheres whose centres share one coordinate exactly (the reference's grid of small spheres sits at
+    y = 0.2, config.rs:52-110) go to a scan list of their own whose tests fold that coordinate into per-ray constants
+    (rt_device.h, ScanLists::plan).  Here the shared coordinate is on each axis in turn, next to static spheres off
+    the plane, moving spheres, a ground and a larger sphere: ray batches (camera rays, rays lying IN the plane, rays along the
+    plane's normal) against the oracle, a render against the oracle at path level, and both bit for bit against the
+    same scene with the planar list switched off (rt_debug_set_planar_list)."""
+    rng = np.random.default_rng(50 + axis)
+    n_plane, n_off, n_mov = 420, 150, 60
+    n = 2 + n_plane + n_off + n_mov
+    c0 = np.empty((n, 3), np.float32)
+    c0[:, 0] = rng.uniform(-12, 12, n); c0[:, 1] = rng.uniform(-12, 12, n); c0[:, 2] = rng.uniform(-12, 12, n)
+    plane = np.float32(0.7)
+    rad = rng.uniform(0.15, 0.4, n).astype(np.float32)
+    dc = np.zeros((n, 3), np.float32)
+    c0[2:2 + n_plane, axis] = plane
+    c0[2 + n_plane:, axis] = rng.uniform(1.5, 4.0, n_off + n_mov)  # off the plane, on the camera's side of it
+    dc[2 + n_plane + n_off:] = rng.uniform(-0.4, 0.4, (n_mov, 3))
+    ground = np.zeros(3, np.float32); ground[axis] = -1000.0
+    c0[0] = ground; rad[0] = 1000.0 + 0.3                     # a "ground" under the plane, normal = the shared axis
+    c0[1] = 0; c0[1, axis] = 6.0; rad[1] = 3.0                # and a larger sphere above it
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_METAL, (0.8, 0.8, 0.6), 0.1, 0, -1),
+            (api.RT_MAT_DIELECTRIC, (1, 1, 1), 0, 1.5, -1)]
+    fs = api.FlatScene(c0, rad, (np.arange(n) % 3).astype(np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))], dc=dc)
+    ctx.upload(fs.scene)
+    lay = ctx.debug_scan_layout()
+    assert lay["planar_axis"] == axis and n_plane <= lay["planar_slots"] < n_plane + 32, lay
+    assert lay["n_big"] >= 1 and lay["static_slots"] >= n_off and lay["moving_slots"] >= n_mov, lay
+
+    eye = np.full(3, 9.0); eye[axis] = 5.0
+    up = np.zeros(3); up[axis] = 1.0
+    cam = api.camera_build(tuple(eye), (0, 0, 0), view_up=tuple(up), vfov_degrees=55.0, aspect_ratio=1.5, aperture=0.05,
+                           focus_dist=14.0, shutter=(0.0, 1.0))
+    m = 32768
+    rays = ctx.camera_rays(cam, rng.random((m, 2), dtype=np.float32), rng.random((m, 4), dtype=np.float32))
+    # rays lying in the plane (origin on it, no direction component along the axis): every planar sphere on the line is
+    # cut through its centre; and rays along the normal through sphere centres
+    k = 4096
+    inpl = rays[:k].copy()
+    o = rng.uniform(-14, 14, (k, 3)).astype(np.float32); o[:, axis] = plane
+    d = rng.normal(size=(k, 3)).astype(np.float32); d[:, axis] = 0
+    inpl["origin"], inpl["dir"] = o, d
+    norm = rays[:k].copy()
+    tgt = c0[2 + rng.integers(0, n_plane, k)]
+    o = tgt.copy(); o[:, axis] = 9.0
+    d = np.zeros((k, 3), np.float32); d[:, axis] = -1.0
+    norm["origin"], norm["dir"] = o, d
+    batch = np.concatenate([rays, inpl, norm])
+    got = ctx.intersect_batch(batch)
+    exp = orc.intersect_batch(fs.scene, batch)
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
+    on_plane = (exp["hit"] == 1) & (exp["sphere_id"] >= 2) & (exp["sphere_id"] < 2 + n_plane)
+    print("axis", axis, lay, st, "hits on planar spheres", int(on_plane.sum()))
+    assert on_plane.sum() > 6000
+
+    p = api.make_params(96, 64, 16, max_depth=12, seed=4)
+    img, s1 = ctx.render(cam, p)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+    ctx.debug_set_planar_list(False)
+    try:
+        ctx.upload(fs.scene)
+        assert ctx.debug_scan_layout()["planar_slots"] == 0
+        got2 = ctx.intersect_batch(batch)
+        img2, s2 = ctx.render(cam, p)
+    finally:
+        ctx.debug_set_planar_list(True)
+    assert got.tobytes() == got2.tobytes()
+    assert np.array_equal(img, img2) and s1.rays_traced == s2.rays_traced
 
 
 def test_empty_world_is_all_sky(ctx, api, orc):

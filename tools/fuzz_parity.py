@@ -1,4 +1,4 @@
-"""Debug: random caller-built scenes (sizes, radii over two decades, motion on random axes, big spheres) and random ray
+"""Debug: random caller-built scenes (sizes, radii over two decades, motion on random axes, big spheres, centres in a common plane) and random ray
 batches through rt_intersect_batch against the oracle, with the tests' bar (tests/helpers.py::check_hits)."""
 import os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
@@ -18,6 +18,11 @@ for case in range(n_cases):
     ext = float(rng.choice([1.0, 10.0, 50.0]))
     c0 = rng.uniform(-ext, ext, (n, 3)).astype(np.float32)
     rad = (ext * 10 ** rng.uniform(-2.5, -0.7, n)).astype(np.float32)
+    rng_p = np.random.default_rng(10**6 + seed0 + case)  # (its own stream: the scenes of earlier runs keep their seeds)
+    planar = -1
+    if rng_p.random() < 0.5:  # some or all centres in one plane: the planar scan list when >= 160 of them stay static
+        planar = int(rng_p.integers(0, 3))
+        c0[rng_p.random(n) < rng_p.uniform(0.3, 1.0), planar] = np.float32(rng_p.uniform(-ext, ext))
     dc = np.zeros((n, 3), np.float32)
     mode = int(rng.integers(0, 4))
     if mode:  # 1: one axis, 2: two axes, 3: all
@@ -30,6 +35,7 @@ for case in range(n_cases):
     mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0)]
     fs = api.FlatScene(c0, rad, np.zeros(n, np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))], dc=dc)
     ctx.upload(fs.scene)
+    planar_slots = ctx.debug_scan_layout()["planar_slots"]
     m = 16384
     rays = np.zeros(m, api.ray_dtype)
     o = rng.uniform(-2 * ext, 2 * ext, (m, 3))
@@ -44,6 +50,6 @@ for case in range(n_cases):
     try:
         st = check_hits(got, exp, 1.0, 1e-5, max_excluded=0.1)  # rays that start inside / on big spheres: many t_min-boundary cases
     except AssertionError as e:
-        print("CASE", seed0 + case, "n", n, "ext", ext, "motion axes", mode, "big", n_big, "FAILED:", str(e)[:300], flush=True)
+        print("CASE", seed0 + case, "n", n, "ext", ext, "motion axes", mode, "big", n_big, "plane axis", planar, "FAILED:", str(e)[:300], flush=True)
         continue
-    print("case", seed0 + case, "n", n, "ext", ext, "motion axes", mode, "big", n_big, st, "hits", int(exp["hit"].sum()), flush=True)
+    print("case", seed0 + case, "n", n, "ext", ext, "motion axes", mode, "big", n_big, "plane axis", planar, "planar slots", planar_slots, st, "hits", int(exp["hit"].sum()), flush=True)

@@ -22,6 +22,9 @@ for case in range(n_cases):
     n = int(rng.choice([2, 9, 40, 150, 600]))
     c0 = np.empty((n, 3), np.float32)
     c0[:, 0] = rng.uniform(-8, 8, n); c0[:, 1] = rng.uniform(0.2, 3, n); c0[:, 2] = rng.uniform(-8, 8, n)
+    rng_p = np.random.default_rng(10**6 + seed0 + case)  # (its own stream: the scenes of earlier runs keep their seeds)
+    if rng_p.random() < 0.5:  # some or all centres in one plane (the planar scan list when enough of them stay static)
+        c0[rng_p.random(n) < rng_p.uniform(0.3, 1.0), int(rng_p.integers(0, 3))] = np.float32(rng_p.uniform(0.2, 3))
     rad = rng.uniform(0.1, 0.6, n).astype(np.float32)
     dc = np.zeros((n, 3), np.float32)
     mode = int(rng.integers(0, 4))
