@@ -211,8 +211,10 @@ def main():
                         f"{args.width}x{args.height} @ {args.spp} spp in total, sample-partitioned over {world_size} GPU(s) "
                         f"({count} spp on rank 0) + RCCL reduce, max_depth {args.max_depth}, scene seed 1")
         else:
-            workload = (f"configs[1]: RTIOW final scene (static, {model['n_static'] + model['n_moving']} spheres) "
-                        f"{args.width}x{args.height} @ {args.spp} spp per GPU, max_depth {args.max_depth}, "
+            what = (f"configs[1]: RTIOW final scene (static, {model['n_static'] + model['n_moving']} spheres)"
+                    if args.scene == "FinalStatic" else
+                    f"scene {args.scene} ({model['n_static']} static + {model['n_moving']} moving spheres; NOT the headline workload)")
+            workload = (f"{what} {args.width}x{args.height} @ {args.spp} spp per GPU, max_depth {args.max_depth}, "
                         f"scene seed 1; N GPUs render N*{args.spp} spp (spp_offset = rank*{args.spp}) + RCCL reduce")
         out = {
             "metric": "samples/sec + Mrays/s, RTIOW final scene 1200x800, 1->8 GPUs; % fp32 peak",
