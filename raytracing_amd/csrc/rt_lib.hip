@@ -92,9 +92,9 @@ constexpr uint32_t kOrphan = 0xFFFFFFFFu;         // PathState::acc_idx of a pat
 __host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (size_t)acc_bufs * kTileAcc * sizeof(unsigned long long) + 16; }
 
 #ifndef RT_WAVES_PER_EU
-#define RT_WAVES_PER_EU 3  // 168 VGPRs.  Four waves per SIMD (128 VGPRs) spill ~60 dwords per lane and measure +1 %; a build
-                           // held to two (170 VGPRs, no spill at all) measures the same as three within 0.2 % on
-                           // configs[1] and Random and 1 % faster on PerlinNoise2: the VALU pipes are busy either way
+#define RT_WAVES_PER_EU 3  // 168 VGPRs.  Four waves per SIMD (128 VGPRs) spill ~60 dwords per lane and measure +1 %; two
+                           // (a build that takes 174 VGPRs, nothing spilled) measure +24 % on configs[1] and +23 % on
+                           // Random: the third wave is needed to keep the VALU pipes busy, a fourth is not
 #endif
 // Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
 #ifdef RT_CENSUS
