@@ -60,6 +60,14 @@ def scene_model(api, world):
             "flops_per_ray": FLOPS_STATIC * n_static + FLOPS_MOVING * n_moving, "flops_per_noise_hit": tex_flops}
 
 
+def layout_of(ctx, model):
+    """rt_debug_scan_layout of the uploaded scene; for a library build older than that hook (tools/ab_scenes.sh
+    compares such builds) the variant every BASELINE scene ran then."""
+    if hasattr(ctx.lib, "rt_debug_scan_layout"):
+        return ctx.debug_scan_layout()
+    return {"noise": 1 if model["flops_per_noise_hit"] else 0, "tile_buffers": 2, "planar_slots": 0}
+
+
 def roofline_of(model, rays, samples, kernel_ms, launches, layout):
     """fp32 VALU roofline of the render kernel: algorithmic flops = sphere tests for every ray segment + (noise
     scenes) the texture arithmetic of every hit (hits = rays - samples: each path ends with exactly one miss)."""
@@ -201,7 +209,7 @@ def main():
 
     if rank == 0:
         value = samples_per_step * args.steps / dt
-        roof = roofline_of(model, rays, samples_rank, kernel_ms, launches, ctx.debug_scan_layout())  # this rank's kernel
+        roof = roofline_of(model, rays, samples_rank, kernel_ms, launches, layout_of(ctx, model))  # this rank's kernel
         traffic = measured_traffic(args.scene, args.width, args.height, count)
         roof["traffic"] = traffic  # HBM bytes per launch, PMC passes of THIS workload (profiles/), else null
         roof["traffic_frac_of_hbm_peak"] = (traffic / (roof["kernel_ms_per_launch"] * 1e-3) / 8e12) if traffic else None
@@ -276,7 +284,7 @@ def extra_configs(api, torch, ctx, dev, runs=3):
         finite = bool(torch.isfinite(acc).all().item())
         del acc
         roof = roofline_of(model, int(st.rays_traced), int(st.samples), float(st.kernel_ms), int(st.n_launches),
-                           ctx.debug_scan_layout())
+                           layout_of(ctx, model))
         roof["traffic"] = measured_traffic(scene, W, H, spp)
         res.append({
             "config": tag, "scene": scene, "width": W, "height": H, "spp": spp, "spp_offset": off,
