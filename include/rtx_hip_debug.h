@@ -31,7 +31,8 @@ int rt_debug_set_tile_buffers(rt_ctx* ctx, int n);
 
 /* How the last rt_upload_scene laid the world out for the scan, for tests and for bench.py's kernel name:
  * out = {big spheres, general static slots, planar slots, moving slots (each padded to whole chunks of 8),
- *        planar axis (0/1/2, -1 without a planar list), moving-list axis count (7 general / 2 y-only / 0 none),
+ *        planar axis (0/1/2, -1 without a planar list), bit mask of the axes some moving sphere moves along (bit 0 =
+ *        x; 2 = y only: the instantiation without the x and z interpolation; 0 without moving spheres),
  *        tile buffers per wave, noise variant (0/1)}. */
 int rt_debug_scan_layout(rt_ctx* ctx, int32_t out[8]);
 
