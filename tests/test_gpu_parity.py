@@ -551,6 +551,49 @@ def test_planar_scan_list(ctx, api, orc, axis):
     assert np.array_equal(img, img2) and s1.rays_traced == s2.rays_traced
 
 
+def test_large_planar_list_walks_its_bound_levels(ctx, api, orc):
+    """8192 small spheres on a 128 x 64 grid in the plane y = 0.3 (+ a ground): a planar list long enough for its
+    upper bound levels to be switched on (16- and 64-sphere nodes are small against the scene), so the hierarchical
+    form of the planar walk runs in full waves, not only in the sparse passes at the end of a render.  Ray batch
+    against the oracle, and batch and render bit for bit against the general list."""
+    rng = np.random.default_rng(77)
+    gx, gz = np.meshgrid(np.arange(128), np.arange(64), indexing="ij")
+    n = 1 + gx.size
+    c0 = np.empty((n, 3), np.float32)
+    c0[1:, 0] = (gx.ravel() - 64) * 0.5 + rng.uniform(-0.12, 0.12, gx.size)
+    c0[1:, 1] = np.float32(0.3)
+    c0[1:, 2] = (gz.ravel() - 32) * 0.5 + rng.uniform(-0.12, 0.12, gx.size)
+    rad = np.full(n, 0.1, np.float32)
+    rad[1:] = rng.uniform(0.05, 0.1, n - 1)
+    c0[0] = (0, -1000, 0); rad[0] = 1000.0
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_METAL, (0.8, 0.8, 0.6), 0.0, 0, -1)]
+    fs = api.FlatScene(c0, rad, (np.arange(n) % 2).astype(np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))])
+    ctx.upload(fs.scene)
+    lay = ctx.debug_scan_layout()
+    assert lay["planar_axis"] == 1 and lay["planar_slots"] == 8192 and lay["static_slots"] == 0, lay
+    cam = api.camera_build((20, 6, 14), (0, 0, 0), vfov_degrees=50.0, aspect_ratio=1.5, aperture=0.0, focus_dist=10.0)
+    m = 65536
+    rays = ctx.camera_rays(cam, rng.random((m, 2), dtype=np.float32), rng.random((m, 4), dtype=np.float32))
+    got = ctx.intersect_batch(rays)
+    exp = orc.intersect_batch(fs.scene, rays)
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
+    small = (exp["hit"] == 1) & (exp["sphere_id"] >= 1)
+    print(lay, st, "hits on the grid", int(small.sum()))
+    assert small.sum() > 8000
+    p = api.make_params(96, 64, 8, max_depth=8, seed=5)
+    img, s1 = ctx.render(cam, p)
+    ctx.debug_set_planar_list(False)
+    try:
+        ctx.upload(fs.scene)
+        assert ctx.debug_scan_layout()["planar_slots"] == 0
+        got2 = ctx.intersect_batch(rays)
+        img2, s2 = ctx.render(cam, p)
+    finally:
+        ctx.debug_set_planar_list(True)
+    assert got.tobytes() == got2.tobytes()
+    assert np.array_equal(img, img2) and s1.rays_traced == s2.rays_traced
+
+
 def test_empty_world_is_all_sky(ctx, api, orc):
     """HitList with no objects (hit.rs:100-110 returns None): every ray misses, every sample is the sky gradient
     (main.rs:133-138); one ray per sample."""
