@@ -248,6 +248,58 @@ def test_six_noise_textures_in_one_scene(ctx, api, orc):
     ctx.upload(fs.scene)  # the context still works after the refusal
 
 
+def test_noise_textures_on_a_planar_grid(ctx, api, orc):
+    """The kernel variants with noise textures AND the planar scan list compiled in, which no factory scene runs
+    (their noise scenes have two spheres): a grid of 256 spheres in the plane y = 0.35, Lambertian with two noise
+    textures, metal and glass, on a noise-textured ground.  Render against the oracle at path level, with two tile
+    buffers per wave and with one, and bit for bit against the general list."""
+    srcs = ["PerlinTurbulence", "ValueMarbled"]
+    worlds = [api.World(n, seed=1) for n in srcs]
+    tables = [api.NoiseTable.from_buffer_copy(w.scene.noise_tables[0]) for w in worlds]
+    texs = []
+    for k, w in enumerate(worlds):
+        s = w.scene
+        t = next(api.Texture.from_buffer_copy(s.textures[i]) for i in range(s.n_textures)
+                 if s.textures[i].kind in (api.RT_TEX_VALUE_NOISE, api.RT_TEX_PERLIN_NOISE))
+        t.table_id = k
+        texs.append(t)
+    rng = np.random.default_rng(12)
+    gx, gz = np.meshgrid(np.arange(16), np.arange(16), indexing="ij")
+    n = 1 + gx.size
+    c0 = np.empty((n, 3), np.float32)
+    c0[1:, 0] = (gx.ravel() - 8) * 0.9 + rng.uniform(0, 0.3, gx.size)
+    c0[1:, 1] = np.float32(0.35)
+    c0[1:, 2] = (gz.ravel() - 8) * 0.9 + rng.uniform(0, 0.3, gx.size)
+    rad = np.full(n, 0.35, np.float32)
+    c0[0] = (0, -1000, 0); rad[0] = 1000.0
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0), (api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 1),
+            (api.RT_MAT_METAL, (0.8, 0.8, 0.6), 0.1, 0, -1), (api.RT_MAT_DIELECTRIC, (1, 1, 1), 0, 1.5, -1)]
+    mid = rng.integers(0, 4, n).astype(np.uint32)
+    mid[0] = 0
+    fs = api.FlatScene(c0, rad, mid, mats, texs, noise_tables=tables)
+    cam = api.camera_build((9, 4, 7), (0, 0.3, 0), vfov_degrees=45.0, aspect_ratio=96 / 64)
+    p = api.make_params(96, 64, 16, max_depth=10, seed=3)
+    ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
+    res = {}
+    for planar, bufs in ((True, 0), (True, 1), (False, 0)):
+        ctx.debug_set_planar_list(planar)
+        ctx.debug_set_tile_buffers(bufs)
+        try:
+            ctx.upload(fs.scene)
+            lay = ctx.debug_scan_layout()
+            assert lay["noise"] == 1 and (lay["planar_slots"] == 256) == planar and lay["tile_buffers"] == (bufs or 2), lay
+            res[(planar, bufs)] = ctx.render(cam, p)
+        finally:
+            ctx.debug_set_planar_list(True)
+            ctx.debug_set_tile_buffers(0)
+    img, st = res[(True, 0)]
+    r = rmse_gamma(img, ref)
+    print("render rmse(gamma)", r, "rays", int(st.rays_traced), rays_ref)
+    assert r < 0.02 and abs(int(st.rays_traced) - rays_ref) < 0.01 * rays_ref
+    for key in ((True, 1), (False, 0)):
+        assert np.array_equal(res[key][0], img) and res[key][1].rays_traced == st.rays_traced, key
+
+
 def test_render_path_level_parity_small(ctx, api):
     """Same counter RNG + same maps => the GPU image follows the oracle's sample for sample; only rays whose
     fp32 decisions flip differ. 100x56 @ 16 spp against the committed oracle image."""
