@@ -438,15 +438,19 @@ def test_work_unit_size_does_not_change_the_image(ctx, api):
     w = api.World("FinalStatic", seed=1, aspect=1.5)
     p = api.make_params(150, 100, 24, seed=w.render_seed)
     res = []
-    for planar in (True, False):
+    for planar, bufs in ((True, 0), (False, 0), (True, 1)):
         ctx.debug_set_planar_list(planar)
+        ctx.debug_set_tile_buffers(bufs)
         try:
             ctx.upload(w.scene)
-            assert (ctx.debug_scan_layout()["planar_slots"] > 0) == planar
+            lay = ctx.debug_scan_layout()
+            assert (lay["planar_slots"] > 0) == planar and lay["tile_buffers"] == (bufs or 2), lay
             res.append(ctx.render(w.camera, p))
         finally:
             ctx.debug_set_planar_list(True)
-    assert np.array_equal(res[0][0], res[1][0]) and res[0][1].rays_traced == res[1][1].rays_traced
+            ctx.debug_set_tile_buffers(0)
+    for img, st in res[1:]:
+        assert np.array_equal(res[0][0], img) and res[0][1].rays_traced == st.rays_traced
 
 
 @pytest.mark.parametrize("W,H,spp", [(2, 2, 64), (3, 5, 33), (9, 7, 16), (65, 2, 9), (8, 8, 1)])
