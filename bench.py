@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--max-depth", type=int, default=100)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-configs", action="store_true")
+    ap.add_argument("--allow-lib-override", action="store_true",
+                    help="A/B tooling: honour RTX_HIP_LIB (otherwise a set RTX_HIP_LIB is an error); the JSON line "
+                         "names the file that ran either way")
     args = ap.parse_args()
     strong = args.mode == "strong4k"
     args.width = args.width or (3840 if strong else 1200)
@@ -121,6 +124,8 @@ def main():
     import torch
     from raytracing_amd import api
     from raytracing_amd import dist as rdist
+    if args.allow_lib_override:
+        api.allow_lib_override()
 
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -247,6 +252,7 @@ def main():
             "rays_per_sample": rays / samples_rank,
             "fp32_peak_frac": roof["frac"],
             "roofline": roof,
+            "library": api.lib_provenance(),  # the file that ran: absolute path, sha256, whether it is the in-tree build
         }
         if world_size == 1 and not args.no_extra_configs:
             del acc

@@ -17,7 +17,8 @@ from typing import Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("RTX_HIP_LIB") or os.path.join(_HERE, "librtx_hip.so")  # env override: A/B builds
+LIB_PATH = os.path.join(_HERE, "librtx_hip.so")  # the in-tree build; see allow_lib_override()
+_override_allowed = False
 
 RT_OK = 0
 RT_ERR_BAD_ARG = -1
@@ -128,11 +129,38 @@ class RtError(RuntimeError):
         self.code = code
 
 
+def allow_lib_override() -> None:
+    """A/B tooling only (bench.py --allow-lib-override, tools/): let the environment variable RTX_HIP_LIB name the
+    library file to load instead of the in-tree build.  Without this call a set RTX_HIP_LIB is an ERROR, so that no
+    test or measurement can silently run another file than the one in the tree."""
+    global _override_allowed
+    _override_allowed = True
+
+
+def lib_provenance() -> dict:
+    """Absolute path and sha256 of the library file actually loaded (bench.py prints it in its JSON line)."""
+    import hashlib
+    load()
+    with open(_lib_path, "rb") as f:
+        digest = hashlib.sha256(f.read()).hexdigest()
+    return {"path": _lib_path, "sha256": digest, "in_tree": os.path.realpath(_lib_path) == os.path.realpath(LIB_PATH)}
+
+
+_lib_path = None
+
+
 def load() -> C.CDLL:
     """Load librtx_hip.so (built by raytracing_amd/csrc/Makefile). Raises if it is missing."""
-    global _lib
+    global _lib, _lib_path
     if _lib is not None:
         return _lib
+    path = LIB_PATH
+    env = os.environ.get("RTX_HIP_LIB")
+    if env:
+        if not _override_allowed:
+            raise RuntimeError("RTX_HIP_LIB is set but library overrides are not allowed here "
+                               "(bench.py: --allow-lib-override; tools: api.allow_lib_override())")
+        path = os.path.abspath(env)
     # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64. Two HIP runtimes in one process
     # cannot both own the GPU ("No HIP GPUs are available" in whichever initialises second), so when torch is
     # installed let it load its runtime FIRST: our DT_NEEDED libamdhip64.so.7 then binds to that same copy.
@@ -140,11 +168,12 @@ def load() -> C.CDLL:
         import torch  # noqa: F401
     except Exception:
         pass
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise FileNotFoundError(
-            f"{LIB_PATH} not found: build it with `make -C raytracing_amd/csrc` "
+            f"{path} not found: build it with `make -C raytracing_amd/csrc` "
             "(or __graft_entry__.build()). There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
+    _lib_path = path
     vp = C.c_void_p
     lib.rt_create.argtypes = [C.c_int, C.POINTER(vp)]
     lib.rt_destroy.argtypes = [vp]

@@ -102,6 +102,7 @@ struct ScanLists {
     int32_t ns_pad, nm_pad;
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
     float cmax;             // max |c| over the static list, in the scan frame
+    float key_eps0;         // absolute part of a key's error bound: kKeyEps0 * max(|c| + r) over the scan lists (scan frame)
     int32_t mov_axes;       // bit k set: some moving sphere has dc[k] != 0 (terms_moving skips the other axes)
     int32_t stat_levels, mov_levels;  // bit L >= 1 set: bound level L is worth testing for this list (upload decides)
     // the same for a wave with at most kSparseRays live rays (the end of a launch, when the last long paths are traced
@@ -130,7 +131,8 @@ struct ShadeRec {
 static_assert(sizeof(ShadeRec) == 48, "ShadeRec layout");
 struct DevScene {
     ScanLists lists;
-    const int32_t* scan_id;  // scan slot (static slots first, then moving) -> sphere id
+    const int32_t* scan_id;  // scan slot (static slots first, then planar, then moving) -> sphere id
+    const int32_t* id_slot;  // sphere id -> its scan slot, -1 for a big sphere
     // spheres too large for the fp32 scan (|c|,r >> 1: e.g. the r = 1000 ground): f64 test
     const int32_t* big_id;
     const BigSphere* big;  // n_big records, in big_id order
@@ -392,21 +394,24 @@ struct Floor {
 };
 // The root: "near root if it is in range, else the far root" (shape.rs:53-61) with the range start folded into
 // o': as unsigned bit patterns a negative float loses to any non-negative one, so the root taken is
-// umin(bits(b - s), bits(b + s)), and v_min3_u32 with the best so far gives the new best in one instruction.
+// umin(bits(b - s), bits(b + s)).
+// `second` is the runner-up KEY (no slot): the smallest key among the candidates that did not become `best`
+// (v_med3_u32 keeps best <= second).  hit_end compares it with the exact (f64) depth of the accepted nominee: when
+// some other candidate's key does not lie safely beyond it, the ray is traced again from that nominee on and the next
+// candidate is decided in f64 as well, so near-ties are ordered by their f64 depths, not by fp32 keys.
 template <bool kFloor>
-__device__ __forceinline__ void take_root(float b, float disc, int slot, int lo, int ls, uint32_t& best, int& idx) {
+__device__ __forceinline__ void take_root(float b, float disc, int slot, int lo, int ls, uint32_t& best, uint32_t& second,
+                                          int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
     const uint32_t k1 = __float_as_uint(b - s), k2 = __float_as_uint(b + s);
-    if (kFloor) {
-        const uint32_t key = min(k1, k2);
-        const bool closer = key < best && (int)key > lo - (slot > ls ? 1 : 0);
-        best = closer ? key : best;
-        idx = closer ? slot : idx;
-    } else {
-        const uint32_t nb = min(min(k1, k2), best);  // v_min3_u32
-        idx = nb != best ? slot : idx;               // strictly closer
-        best = nb;
-    }
+    uint32_t key = min(k1, k2);
+    if (kFloor) key = ((int)key > lo - (slot > ls ? 1 : 0)) ? key : 0xFFFFFFFFu;  // at or before the floor: decided already
+#ifndef RT_X_NOSECOND
+    second = max(min(key, best), min(max(key, best), second));  // v_med3_u32
+#endif
+    const uint32_t nb = min(key, best);
+    idx = nb != best ? slot : idx;  // strictly closer: the first of two equal keys stays (the other is `second`)
+    best = nb;
 }
 
 #ifdef RT_STATS
@@ -421,8 +426,8 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 // direct-form b and disc of sphere k for both rays.
 template <bool kFloor, class Direct>
 __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direct&& direct, int slot0, const Floor& fl,
-                                               uint32_t& best_a, uint32_t& best_b, int& idx_a, int& idx_b,
-                                               unsigned* dbg) {
+                                               uint32_t& best_a, uint32_t& best_b, uint32_t& second_a, uint32_t& second_b,
+                                               int& idx_a, int& idx_b, unsigned* dbg) {
 #pragma unroll
     for (int k = 0; k < kGroup; ++k) {
         const int hit = max(__float_as_int(filter[k].x), __float_as_int(filter[k].y));
@@ -431,8 +436,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direc
             direct(k, b, disc);
             RT_STAT(2, 1);
             RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc.x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc.y >= 0)));
-            take_root<kFloor>(b.x, disc.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, idx_a);
-            take_root<kFloor>(b.y, disc.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, idx_b);
+            take_root<kFloor>(b.x, disc.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, second_a, idx_a);
+            take_root<kFloor>(b.y, disc.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, second_b, idx_b);
         }
     }
 }
@@ -449,7 +454,8 @@ __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direc
 // are neighbours and the groups a wave's rays meet are few.
 template <bool kFloor, bool kPlanar>
 __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, const Floor& fl, uint32_t& best_a,
-                                             uint32_t& best_b, int& idx_a, int& idx_b) {
+                                             uint32_t& best_b, uint32_t& second_a, uint32_t& second_b, int& idx_a,
+                                             int& idx_b) {
     unsigned dbg[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     const cv4p st = as_scalar(S.stat);
         auto group = [&](const v4f (&sp)[kGroup], int base) {
@@ -493,7 +499,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                     f2 q;
                     terms_static_direct(sp[k], nr2[k], r, b, q);
                     d = fma2(b, b, -q);
-                }, base, fl, best_a, best_b, idx_a, idx_b, dbg);
+                }, base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         };
     // HIERARCHICAL CULLING.  Upload stores a bounding sphere around each group of kGroup list neighbours (Morton
@@ -537,7 +543,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                     f2 q;
                     terms_static_direct(sp[k], nr2[k], r, b, q);
                     d = fma2(b, b, -q);
-                }, S.ns_pad + base, fl, best_a, best_b, idx_a, idx_b, dbg);
+                }, S.ns_pad + base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         });
     };
@@ -606,7 +612,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             if (RT_TAILCOND) {
                 RT_STAT(1, 1);
                 roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + S.np_pad + base, fl,
-                                       best_a, best_b, idx_a, idx_b, dbg);
+                                       best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         });
     };
@@ -622,8 +628,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
 // ------------------------------------------------------------------ the f64 sphere test
 // shape.rs:35-65 / :101-133 verbatim in f64 on the fp32 inputs, unnormalised direction:
 // near root if t_min <= t < t_max else far root.  The fp32 scan only NOMINATES a sphere; this f64 test DECIDES
-// it, so a grazing or far-origin false positive of the scan is rejected here (the ray then keeps its big-sphere
-// hit or misses).  `clamp_disc` clamps nothing but f64 rounding noise (|disc| < 1e-14 hb^2) to a tangent hit.
+// it, so a grazing or far-origin false positive of the scan is rejected here.
 // f64 reciprocal and square root without the library's scaling and special cases (12 and 22 VALU instructions as
 // compiled from 1.0 / a and sqrt(x)): the arguments here are |d|^2 of an fp32 direction and a discriminant of fp32
 // inputs, normal f64 numbers or exactly 0.  v_rcp_f64 / v_rsq_f64 seed two Newton steps (rcp: <= 1 ulp) or one
@@ -658,14 +663,13 @@ __device__ __forceinline__ void sphere_centre_f64(const DevScene& S, const float
     }
 }
 __device__ __forceinline__ bool sphere_roots_f64(double cx, double cy, double cz, double r2, const Ray& r, double a,
-                                                 double inv_a, double t_min, double t_max, bool clamp_disc, double& t_out) {
+                                                 double inv_a, double t_min, double t_max, double& t_out) {
     const double ocx = (double)r.o.x - cx, ocy = (double)r.o.y - cy, ocz = (double)r.o.z - cz;
     const double dx = r.d.x, dy = r.d.y, dz = r.d.z;
     const double hb = ocx * dx + ocy * dy + ocz * dz;
     const double c = ocx * ocx + ocy * ocy + ocz * ocz - r2;
-    double disc = hb * hb - a * c;
-    if (clamp_disc && disc < 0.0 && disc > -1e-14 * hb * hb) disc = 0.0;  // f64 rounding only
-    if (!(disc >= 0.0)) return false;
+    const double disc = hb * hb - a * c;
+    if (!(disc >= 0.0)) return false;  // shape.rs:41
     const double root = sqrt_f64(disc);
     double t = (-hb - root) * inv_a;  // one f64 reciprocal per ray instead of a division per root
     bool ok = (t >= t_min) && (t < t_max);
@@ -677,13 +681,19 @@ __device__ __forceinline__ bool sphere_roots_f64(double cx, double cy, double cz
     t_out = t;
     return true;
 }
+// HitList::hit keeps the FIRST object in world order among those hit at exactly the same t (hit.rs:100-110: the
+// range is narrowed to the closest t so far and is half-open).  The device meets candidates in another order (big
+// spheres, then fp32-key order), so "closer" is (t, id) lexicographic.
+__device__ __forceinline__ bool closer_hit(double t, int id, double t_best, int id_best) {
+    return t < t_best || (t == t_best && id < id_best);
+}
 // Per-ray state kept across the packed scan: the f64 big-sphere result before it, the f64 hit record after it.
 // Kept small (7 VGPRs per ray): everything else is recomputed after the scan from the ray and the winner's id.
 struct HitWork {
     double t_best;
     double inv_a;  // 1 / |d|^2, f64
     int id_best;
-    float inv_len;
+    float key_scale;  // |d| * kScanInflate: t -> key units (see hit_key)
 };
 // The scan is CONSERVATIVE and the f64 test decides: the scan direction is the unit direction times (1 + 8 ulp),
 // which inflates b^2 by 16 ulp -- more than the worst-case rounding of disc = b^2 - (|oc|^2 - r^2), ~15 ulp of
@@ -692,24 +702,73 @@ struct HitWork {
 // |oc| / r is (a radius-0.1 sphere 300 away is hit or missed at random by a plain fp32 discriminant); the price is
 // a band of false nominations, which the f64 test of the nominee rejects (HitRec::kRetry below).
 constexpr float kScanInflate = 1.0f + 8.0f / 16777216.0f;
+// How far a KEY can lie above the exact depth of its sphere, in key units (distance along the ray from the scan's
+// start).  The inflation biases every near-root key downwards (d(b - s)/db = -(b - s)/s < 0 outside the sphere), a
+// far-root key (origin inside) upwards by <= 16 ulp; what is left is ABSOLUTE: centres and origin are rounded into
+// the scan frame, 3 half-ulps of the frame coordinates per component of oc, which b and s inherit: <= 16 ulp of
+// (|o'| + |c|).  For an origin farther than 3 C from the frame's origin (C = max(|c| + r) over the lists) every
+// depth exceeds 2/3 |o'| and the bound is < 32 ulp of the depth; nearer, it is < 64 ulp of C.  So
+//   key <= depth * (1 + kKeyRel) + kKeyEps0 * C        (with room for the roundings of hit_key itself)
+// needs no per-ray term: ScanLists::key_eps0 = kKeyEps0 * C is a scene constant.
+constexpr float kKeyRel = 128.0f / 16777216.0f;
+constexpr float kKeyEps0 = 64.0f / 16777216.0f;
+// The scan does not start at t_min but kStartShift of it EARLIER: a root just above t_min (which the reference takes,
+// shape.rs:54 `t_min <= t`) must not come out of the fp32 arithmetic with a negative key and be lost.  Roots inside the
+// shifted-in sliver are nominated, rejected by the f64 test (which uses the true t_min) and passed over (kRetry).
+constexpr float kStartShift = 1.0f / 32.0f;
+__host__ __device__ __forceinline__ float scan_start(float t_min) { return t_min - t_min * kStartShift; }
+// The f64 constants of the closest-hit steps.  The render kernel gets them ready-made in its kernarg segment and reads
+// them where they are used (scalar loads -> SGPR pairs, used straight as f64 operands): left to the compiler, the
+// conversions (double)t_min, (double)origin ... are hoisted out of the persistent loop into ten VGPRs that stay live
+// across all of it (measured: the difference between 2 and 29 spilled VGPRs).
+struct HitConsts {
+    double t_min, t_start;  // the reference's range start (main.rs:116) and where the scan starts
+    double ox, oy, oz;      // ScanLists::ox, oy, oz
+    float key_eps0;         // ScanLists::key_eps0
+    float pad;
+};
+__host__ __device__ inline HitConsts make_hit_consts(const ScanLists& L, float t_min) {
+    return {(double)t_min, (double)scan_start(t_min), (double)L.ox, (double)L.oy, (double)L.oz, L.key_eps0, 0.0f};
+}
 __device__ __forceinline__ double dir_len2(const Ray& r) {
     return (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
 }
-// the key bound a ray brings into the scan from its big-sphere hit (same inflated units as the scan's keys)
-__device__ __forceinline__ uint32_t hit_begin_key(const HitWork& w, double a, float t_min, float& inv_len) {
-    const float len2 = (float)a;
-    inv_len = fast_rsq(len2) * kScanInflate;
+// The exact best depth so far as an UPPER bound in the scan's key units: a candidate whose key is not below it
+// cannot be closer than that hit.
+__device__ __forceinline__ uint32_t hit_key(const HitWork& w, const HitConsts& C) {
     if (w.id_best < 0) return kInfBits;
-    const float tb = (float)((w.t_best - (double)t_min) * (double)(len2 * inv_len));
-    return __float_as_uint(fmaxf(tb, 0.0f));
+    const float tb = (float)(w.t_best - C.t_start) * w.key_scale;  // >= 0: t_best >= t_min > t_start
+    return __float_as_uint(fmaf(tb, 1.0f + kKeyRel, C.key_eps0));
 }
-// HitRec::sphere == kRetry: the scan's nominee (key = bits of HitRec::t) was a false positive of the conservative
-// fp32 test.  The ray is traced AGAIN with that key as the floor `lo` of the scan: candidates at or below it are
-// skipped, so the next-closest candidate gets its f64 test, until one is accepted or none is left.  (Keeping only
-// the nominee and falling back to the sky on a rejection would lose the real hit behind a grazed sphere.)
+// HitRec::sphere == kRetry: the trace of this ray segment is NOT finished.  Either the scan's nominee was a false
+// positive of the conservative fp32 test, or it was accepted but another candidate's key (Hit2::second) lies below
+// its exact depth's bound, so that candidate must be decided in f64 too.  The ray is traced AGAIN with the nominee's
+// (key, slot) as the floor of the scan -- candidates at or before it are skipped -- and with the exact best so far
+// carried along, until no undecided candidate can be closer.  Near-ties are therefore ordered by f64 depths and exact
+// ties by world order, as the reference does; the fp32 keys only decide in which order candidates are looked at.
+// The record of an unfinished trace: sphere = kRetry, t = the floor's key bits, front = the floor's slot in its low
+// 16 bits and, above them, 1 + the scan slot of the best candidate accepted so far (0: none; a big sphere's hit is
+// found again by every pass).  Three registers, as many as a pass-over needed before there was anything to carry: the
+// carried candidate's depth is recomputed by the next pass (same inputs, same code: the same bits).
 constexpr int kRetry = -2;
-__device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float t_min, HitWork& w, uint32_t best,
-                                          int slot) {
+__device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
+__device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? (h.front & 0xFFFF) : 0x7FFFFFFF; }
+__device__ __forceinline__ void merge_carry(const DevScene& S, const Ray& r, const HitConsts& C, HitWork& w, const HitRec& h) {
+    const int cs = h.sphere == kRetry ? (h.front >> 16) - 1 : -1;
+    if (cs >= 0) {
+        const double inf = __longlong_as_double(0x7FF0000000000000ll);
+        double cx, cy, cz, t;
+        float rad;
+        sphere_centre_f64(S, S.slot_a, S.slot_dc, cs, r.time, cx, cy, cz, rad);
+        const int id = S.scan_id[cs];
+        if (sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, C.t_min, inf, t) &&
+            closer_hit(t, id, w.t_best, w.id_best)) {
+            w.t_best = t; w.id_best = id;
+        }
+    }
+}
+__device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, const HitConsts& C, HitWork& w, uint32_t best,
+                                          uint32_t second, int slot) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     HitRec h;
     if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
@@ -717,10 +776,15 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
         double cx, cy, cz, t;
         float rad;
         sphere_centre_f64(S, S.slot_a, S.slot_dc, slot, r.time, cx, cy, cz, rad);
-        if (id >= 0 && sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, (double)t_min, inf, true, t)) {
-            if (t < w.t_best) { w.t_best = t; w.id_best = id; }  // else a big sphere is closer: it keeps the hit
-        } else {
-            h.sphere = kRetry; h.front = slot; h.t = __uint_as_float(best); h.p = {0, 0, 0}; h.n = {0, 0, 0};
+        if (id >= 0 && sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, C.t_min, inf, t) &&
+            closer_hit(t, id, w.t_best, w.id_best)) {
+            w.t_best = t; w.id_best = id;
+        }
+        // every candidate not decided yet has a key >= second: final unless that may still be closer than the best
+        if (second < hit_key(w, C)) {
+            const int carried = w.id_best >= 0 ? S.id_slot[w.id_best] : -1;  // -1: none, or a big sphere
+            h.sphere = kRetry; h.front = slot | ((carried + 1) << 16); h.t = __uint_as_float(best);
+            h.p = {0, 0, 0}; h.n = {0, 0, 0};
             return h;
         }
     }
@@ -747,16 +811,6 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, float
     h.n = {(float)nx, (float)ny, (float)nz};
     return h;
 }
-// the scan floor (key, slot) of a ray whose previous trace ended in kRetry (else key -1: nothing to skip)
-__device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
-__device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? h.front : 0x7FFFFFFF; }
-// the scan with or without the floor, chosen per wave
-template <bool kPlanar>
-__device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Pair& p, const Floor& fl, uint32_t& best_a,
-                                                uint32_t& best_b, int& slot_a, int& slot_b) {
-    if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull) scan_spheres<true, kPlanar>(L, p, fl, best_a, best_b, slot_a, slot_b);
-    else scan_spheres<false, kPlanar>(L, p, fl, best_a, best_b, slot_a, slot_b);
-}
 
 // HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
 // three steps so that a caller can re-read its scene arguments between them (render_kernel):
@@ -765,21 +819,37 @@ __device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Pair& 
 struct Hit2 {
     HitWork wa, wb;
     Pair p;
-    uint32_t best_a, best_b;
+    uint32_t best_a, best_b;      // closest key so far (enters the scan as the bound from the f64 results so far)
+    uint32_t second_a, second_b;  // runner-up key (take_root)
     int slot_a, slot_b;
 };
+// the scan with or without the floor, chosen per wave
+template <bool kPlanar>
+__device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Floor& fl, Hit2& x) {
+    if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull)
+        scan_spheres<true, kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.second_a, x.second_b, x.slot_a, x.slot_b);
+    else
+        scan_spheres<false, kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.second_a, x.second_b, x.slot_a, x.slot_b);
+}
+// prev_a / prev_b: the rays' records of the previous trace; `carry` (wave-uniform) says whether any of them may be a
+// kRetry record whose exact best so far has to be taken over (passes without a retracing lane skip that code).
 template <bool kPlanar>
 __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
-                                              float t_min, Hit2& x) {
+                                              const HitConsts& C, bool carry, const HitRec& prev_a, const HitRec& prev_b,
+                                              Hit2& x) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
     x.best_a = x.best_b = kInfBits;
+    x.second_a = x.second_b = 0xFFFFFFFFu;
     x.wa.id_best = x.wb.id_best = -1;
-    x.wa.inv_len = x.wb.inv_len = 1.0f;
     x.wa.t_best = x.wb.t_best = inf;
     const double aa = dir_len2(ra), ab = dir_len2(rb);
     x.wa.inv_a = rcp_f64(aa);
     x.wb.inv_a = rcp_f64(ab);
-    {  // big spheres, f64, world order: one scalar load per sphere serves both rays
+    if (carry) {  // a retracing lane's best candidate so far, decided again
+        if (do_a) merge_carry(S, ra, C, x.wa, prev_a);
+        if (do_b) merge_carry(S, rb, C, x.wb, prev_b);
+    }
+    {  // big spheres, f64: one scalar load per sphere serves both rays
         typedef double d8 __attribute__((ext_vector_type(8)));
         const RT_AS4 d8* big = (const RT_AS4 d8*)(uintptr_t)S.big;
         const RT_AS4 int32_t* big_id = (const RT_AS4 int32_t*)(uintptr_t)S.big_id;
@@ -790,24 +860,30 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
             auto test = [&](const Ray& r, double a, HitWork& w) {
                 double cx = B[0], cy = B[1], cz = B[2], t;
                 if (moving) { const double tm = (double)r.time; cx += tm * B[4]; cy += tm * B[5]; cz += tm * B[6]; }
-                if (sphere_roots_f64(cx, cy, cz, B[3], r, a, w.inv_a, (double)t_min, w.t_best, false, t)) { w.t_best = t; w.id_best = id; }
+                // world order: strictly closer, unless a carried hit of a LATER sphere is in w (then (t, id) decides)
+                if (sphere_roots_f64(cx, cy, cz, B[3], r, a, w.inv_a, C.t_min, inf, t) &&
+                    (t < w.t_best || (carry && closer_hit(t, id, w.t_best, w.id_best)))) {
+                    w.t_best = t; w.id_best = id;
+                }
             };
             if (do_a) test(ra, aa, x.wa);
             if (do_b) test(rb, ab, x.wb);
         }
     }
-    if (do_a) x.best_a = hit_begin_key(x.wa, aa, t_min, x.wa.inv_len);
-    if (do_b) x.best_b = hit_begin_key(x.wb, ab, t_min, x.wb.inv_len);
+    const float la2 = (float)aa, lb2 = (float)ab;
+    const float inv_la = fast_rsq(la2) * kScanInflate, inv_lb = fast_rsq(lb2) * kScanInflate;
+    x.wa.key_scale = la2 * inv_la;
+    x.wb.key_scale = lb2 * inv_lb;
     Pair& p = x.p;
-    p.dx = f2{ra.d.x * x.wa.inv_len, rb.d.x * x.wb.inv_len};
-    p.dy = f2{ra.d.y * x.wa.inv_len, rb.d.y * x.wb.inv_len};
-    p.dz = f2{ra.d.z * x.wa.inv_len, rb.d.z * x.wb.inv_len};
-    // o' = o + t_min*d - origin in f64, rounded once: its error is an ulp of the SCAN-FRAME coordinate
+    p.dx = f2{ra.d.x * inv_la, rb.d.x * inv_lb};
+    p.dy = f2{ra.d.y * inv_la, rb.d.y * inv_lb};
+    p.dz = f2{ra.d.z * inv_la, rb.d.z * inv_lb};
+    // o' = o + t_start*d - origin in f64, rounded once: its error is an ulp of the SCAN-FRAME coordinate
     const ScanLists& L = S.lists;
-    auto frame = [&](float o, float d, float org) { return (float)(((double)o + (double)t_min * (double)d) - (double)org); };
-    f2 ox = f2{frame(ra.o.x, ra.d.x, L.ox), frame(rb.o.x, rb.d.x, L.ox)};
-    f2 oy = f2{frame(ra.o.y, ra.d.y, L.oy), frame(rb.o.y, rb.d.y, L.oy)};
-    f2 oz = f2{frame(ra.o.z, ra.d.z, L.oz), frame(rb.o.z, rb.d.z, L.oz)};
+    auto frame = [&](float o, float d, double org) { return (float)(((double)o + C.t_start * (double)d) - org); };
+    f2 ox = f2{frame(ra.o.x, ra.d.x, C.ox), frame(rb.o.x, rb.d.x, C.ox)};
+    f2 oy = f2{frame(ra.o.y, ra.d.y, C.oy), frame(rb.o.y, rb.d.y, C.oy)};
+    f2 oz = f2{frame(ra.o.z, ra.d.z, C.oz), frame(rb.o.z, rb.d.z, C.oz)};
     p.time = f2{ra.time, rb.time};
     // a dead ray rides through the packed scan: park it (d = 0, far origin => disc = -|oc|^2 - ... < 0 for every
     // sphere, in either form) so it never sends its wave into a root-extraction group
@@ -819,6 +895,9 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     const f2 oo = fma2(oz, oz, fma2(oy, oy, ox * ox));
     const f2 m = f2{fast_sqrt(oo.x), fast_sqrt(oo.y)} + L.cmax;
     p.qb = fma2(m * m, splat2(-kExpandErr), oo);
+    // the bound a ray brings into the scan: its exact best so far (big spheres, carried candidates)
+    if (do_a) x.best_a = hit_key(x.wa, C);
+    if (do_b) x.best_b = hit_key(x.wb, C);
     if (kPlanar) {  // the planar list's shared coordinate, folded (wave-uniform selects)
         const int ax = L.plan_axis;
         const f2 dk = ax == 0 ? p.dx : ax == 1 ? p.dy : p.dz, mk = ax == 0 ? p.m2ox : ax == 1 ? p.m2oy : p.m2oz;
@@ -828,23 +907,24 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     x.slot_a = x.slot_b = -1;
 }
 __device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
-                                            float t_min, Hit2& x, HitRec& ha, HitRec& hb) {
+                                            const HitConsts& C, Hit2& x, HitRec& ha, HitRec& hb) {
     ha.sphere = -1;
     hb.sphere = -1;
-    if (do_a) ha = hit_end(S, ra, t_min, x.wa, x.best_a, x.slot_a);
-    if (do_b) hb = hit_end(S, rb, t_min, x.wb, x.best_b, x.slot_b);
+    if (do_a) ha = hit_end(S, ra, C, x.wa, x.best_a, x.second_a, x.slot_a);
+    if (do_b) hb = hit_end(S, rb, C, x.wb, x.best_b, x.second_b, x.slot_b);
 }
-// one-shot form for the batch kernel: retraces on the spot while any lane of the wave holds a rejected nominee
+// one-shot form for the batch kernel: retraces on the spot while any lane of the wave holds an unfinished trace
 __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                              float t_min, HitRec& ha, HitRec& hb) {
     ha.sphere = hb.sphere = -1;
     Floor fl = {-1, -1, 0x7FFFFFFF, 0x7FFFFFFF};
+    const HitConsts C = make_hit_consts(S.lists, t_min);
     while (__ballot(do_a || do_b) != 0ull) {  // wave-uniform: every lane runs the packed scan together
         Hit2 x;
         HitRec na, nb;
-        closest_begin<true>(S, ra, rb, do_a, do_b, t_min, x);
-        scan_with_floor<true>(S.lists, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
-        closest_end(S, ra, rb, do_a, do_b, t_min, x, na, nb);
+        closest_begin<true>(S, ra, rb, do_a, do_b, C, true, ha, hb, x);
+        scan_with_floor<true>(S.lists, fl, x);
+        closest_end(S, ra, rb, do_a, do_b, C, x, na, nb);
         if (do_a) { ha = na; fl.lo_a = retry_key(na); fl.ls_a = retry_slot(na); do_a = na.sphere == kRetry; }
         if (do_b) { hb = nb; fl.lo_b = retry_key(nb); fl.ls_b = retry_slot(nb); do_b = nb.sphere == kRetry; }
     }

@@ -58,7 +58,7 @@ struct RenderArgs {
     uint32_t max_depth;
     int32_t antialias;
     uint32_t k0, k1;
-    float t_min;
+    HitConsts hc;            // t_min (main.rs:116), the scan's start and frame origin as f64, ready for the f64 steps
     uint32_t lds_scene_bytes;
     uint32_t acc_bufs;       // tile accumulators per wave in LDS: 2 (current + previous tile) when they fit, else 1
     unsigned long long* accum;  // W*H*3 fixed-point (2^-32) radiance sums
@@ -156,6 +156,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
     };
 
     for (;;) {
+        // The unit-queue state is wave-uniform, but the compiler keeps these loop-carried values in VGPRs (nine of them,
+        // live across the whole pass) unless each is re-declared uniform once per pass: with them in SGPRs no variant of
+        // the kernel spills a VGPR (with them in VGPRs: 5 to 33 spilled, scratch round trips in the scan's cold side).
+        next = __builtin_amdgcn_readfirstlane(next); total = __builtin_amdgcn_readfirstlane(total);
+        tx0 = __builtin_amdgcn_readfirstlane(tx0); ty0 = __builtin_amdgcn_readfirstlane(ty0);
+        tw = __builtin_amdgcn_readfirstlane(tw); npix = __builtin_amdgcn_readfirstlane(npix);
+        s_lo = __builtin_amdgcn_readfirstlane(s_lo); cur_off = __builtin_amdgcn_readfirstlane(cur_off);
+        more = __builtin_amdgcn_readfirstlane((int)more) != 0;
         // ---- unit queue: claim the next unit once this one has no items left and a slot is free
         RT_MARK("claim");
         if (next >= total && more && __ballot(!ps[0].alive || !ps[1].alive) != 0ull) {
@@ -271,22 +279,54 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
         {
             Hit2 x;
-            const Floor fl = {ps[0].alive ? retry_key(h[0]) : -1, ps[1].alive ? retry_key(h[1]) : -1,
+            const bool retry_a = ps[0].alive && h[0].sphere == kRetry, retry_b = ps[1].alive && h[1].sphere == kRetry;
+            const Floor fl = {retry_a ? retry_key(h[0]) : -1, retry_b ? retry_key(h[1]) : -1,
                               retry_slot(h[0]), retry_slot(h[1])};
+            const bool any_retry = __ballot(retry_a || retry_b) != 0ull;  // wave-uniform: most passes have none
             RT_MARK("begin");
-            closest_begin<kPlanar>(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x);
             {
                 const ArgsPtr K = launder(K0);
+                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, 0.0f};
+                closest_begin<kPlanar>(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, any_retry, h[0], h[1], x);
+            }
+            {
+                const ArgsPtr K = launder(K0);
+                const bool sparse_pass = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays;
                 ScanLists L;
-                L.stat = K->S.lists.stat; L.stat_nr2 = K->S.lists.stat_nr2; L.stat_bound = K->S.lists.stat_bound; L.mov_bound = K->S.lists.mov_bound; const bool sparse_pass = __popcll(__ballot(ps[0].alive)) + __popcll(__ballot(ps[1].alive)) <= kSparseRays; L.stat_levels = sparse_pass ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels; L.mov_levels = sparse_pass ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels; L.mov_a = K->S.lists.mov_a; L.mov_b = K->S.lists.mov_b; L.mov_axes = K->S.lists.mov_axes;
-                if (kPlanar) L.plan = K->S.lists.plan, L.plan_nr2 = K->S.lists.plan_nr2; L.plan_bound = K->S.lists.plan_bound; L.np_pad = K->S.lists.np_pad; L.plan_axis = K->S.lists.plan_axis;
-                L.plan_levels = sparse_pass ? K->S.lists.plan_levels_sparse : K->S.lists.plan_levels;
-                L.ns_pad = K->S.lists.ns_pad; L.nm_pad = K->S.lists.nm_pad;
+                L.stat = K->S.lists.stat;
+                L.stat_nr2 = K->S.lists.stat_nr2;
+                L.stat_bound = K->S.lists.stat_bound;
+                L.stat_levels = sparse_pass ? K->S.lists.stat_levels_sparse : K->S.lists.stat_levels;
+                L.ns_pad = K->S.lists.ns_pad;
+                L.mov_a = K->S.lists.mov_a;
+                L.mov_b = K->S.lists.mov_b;
+                L.mov_bound = K->S.lists.mov_bound;
+                L.mov_levels = sparse_pass ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels;
+                L.mov_axes = K->S.lists.mov_axes;
+                L.nm_pad = K->S.lists.nm_pad;
+                if (kPlanar) {  // (the other variant never reads these)
+                    L.plan = K->S.lists.plan;
+                    L.plan_nr2 = K->S.lists.plan_nr2;
+                    L.plan_bound = K->S.lists.plan_bound;
+                    L.plan_axis = K->S.lists.plan_axis;
+                    L.plan_levels = sparse_pass ? K->S.lists.plan_levels_sparse : K->S.lists.plan_levels;
+                }
+                L.np_pad = kPlanar ? K->S.lists.np_pad : 0;  // (slot numbering: read by the moving list's walk too)
                 RT_MARK("scan");
-                scan_with_floor<kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.slot_a, x.slot_b);
+                scan_with_floor<kPlanar>(L, fl, x);
             }
             RT_MARK("end");
-            closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, A.t_min, x, h[0], h[1]);
+            {
+                const ArgsPtr K = launder(K0);
+                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, 0.0f};
+                closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, x, h[0], h[1]);
+            }
+#ifdef RT_STATS
+            {  // g_dbg[7]: ray segments that end this pass unfinished (kRetry: passed over or carried on)
+                const int n_retry = __popcll(__ballot(ps[0].alive && h[0].sphere == kRetry)) + __popcll(__ballot(ps[1].alive && h[1].sphere == kRetry));
+                if (lane == 0 && n_retry) atomicAdd(&g_dbg[7], (unsigned long long)n_retry);
+            }
+#endif
         }
         // ---- paths that end here: the sky (main.rs:133-138) or the depth budget (main.rs:126-130: black, and the
         // scatter whose ray would never be traced is skipped).  A path that stays alive scatters at the top of the
@@ -733,7 +773,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     }
     const float org[3] = {(float)(0.5 * (lo3[0] + hi3[0])), (float)(0.5 * (lo3[1] + hi3[1])), (float)(0.5 * (lo3[2] + hi3[2]))};
     std::vector<float> stat_nr2;
-    double cmax = 0.0;
+    double cmax = 0.0, reach = 0.0;
     // The planar list (ScanLists::plan): the largest set of static small spheres whose centres share one coordinate
     // EXACTLY (compared in the scan frame, where the kernel multiplies them), when it has at least kPlanarMin members.
     // Below that the separate walk costs more than the cheaper tests save (Random, 97 static spheres in y = 0.2:
@@ -796,6 +836,10 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
                 stat_id.push_back((int32_t)i);
             }
             cmax = std::max(cmax, std::sqrt(fx * fx + fy * fy + fz * fz));
+        }
+        if (!is_big[i]) {  // how far from the frame's origin a scan sphere reaches, over its whole motion
+            const double ex = cx + s->dcx[i], ey = cy + s->dcy[i], ez = cz + s->dcz[i];
+            reach = std::max(reach, std::max(std::sqrt(cx * cx + cy * cy + cz * cz), std::sqrt(ex * ex + ey * ey + ez * ez)) + r);
         }
     }
     // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
@@ -950,6 +994,12 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
+    {
+        std::vector<int32_t> id_slot(s->n_spheres, -1);
+        for (size_t k = 0; k < scan_id.size(); ++k)
+            if (scan_id[k] >= 0) id_slot[(size_t)scan_id[k]] = (int32_t)k;
+        UP(dev_copy(c, id_slot.data(), id_slot.size(), &D.id_slot));
+    }
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
     std::vector<BigSphere> big(big_id.size());
     for (size_t k = 0; k < big_id.size(); ++k) {
@@ -1000,6 +1050,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
 #undef UP
     D.lists.ox = org[0]; D.lists.oy = org[1]; D.lists.oz = org[2];
     D.lists.cmax = (float)(cmax * (1.0 + 1e-6));
+    D.lists.key_eps0 = (float)(reach * (1.0 + 1e-6)) * kKeyEps0;
     D.lists.stat_levels = stat_levels; D.lists.mov_levels = mov_levels;
     D.lists.mov_axes = 0;
     for (const float4& v : mov_b) D.lists.mov_axes |= (v.x != 0.0f ? 1 : 0) | (v.y != 0.0f ? 2 : 0) | (v.z != 0.0f ? 4 : 0);
@@ -1082,7 +1133,7 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
     A.max_depth = p->max_depth;
     A.antialias = p->antialias;
     A.k0 = (uint32_t)p->seed; A.k1 = (uint32_t)(p->seed >> 32);
-    A.t_min = p->t_min;
+    A.hc = make_hit_consts(c->S.lists, p->t_min);
     A.lds_scene_bytes = (uint32_t)c->lds_scene;
     A.acc_bufs = c->acc_bufs;
     A.accum = accum;

@@ -18,6 +18,7 @@ else:
     os.environ["RTX_HIP_LIB"] = os.path.join(os.path.dirname(__file__), "..", "raytracing_amd", sys.argv[1])
     sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
     from raytracing_amd import api
+    api.allow_lib_override()  # A/B tooling: RTX_HIP_LIB names the build under test
     ctx = api.Context(0)
     w = api.World("FinalStatic", seed=1, aspect=1.5)
     ctx.upload(w.scene)

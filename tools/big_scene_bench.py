@@ -4,6 +4,7 @@ import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from raytracing_amd import api
+api.allow_lib_override()  # A/B tooling: RTX_HIP_LIB names the build under test
 ctx = api.Context(0)
 for n in (512, 2048, 8192, 16384):
     rng = np.random.default_rng(n)
