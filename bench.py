@@ -65,7 +65,7 @@ def layout_of(ctx, model):
     compares such builds) the variant every BASELINE scene ran then."""
     if hasattr(ctx.lib, "rt_debug_scan_layout"):
         return ctx.debug_scan_layout()
-    return {"noise": 1 if model["flops_per_noise_hit"] else 0, "tile_buffers": 2, "planar_slots": 0}
+    return {"noise": 1 if model["flops_per_noise_hit"] else 0, "tile_buffers": 2, "planar_slots": 0, "scan": 0}
 
 
 def roofline_of(model, rays, samples, kernel_ms, launches, layout):
@@ -73,10 +73,11 @@ def roofline_of(model, rays, samples, kernel_ms, launches, layout):
     scenes) the texture arithmetic of every hit (hits = rays - samples: each path ends with exactly one miss)."""
     flops = rays * model["flops_per_ray"] + max(rays - samples, 0) * model["flops_per_noise_hit"]
     achieved = flops / (kernel_ms * 1e-3) / 1e12
-    # template arguments as rocprofv3 prints them: <noise textures compiled in, two LDS tile buffers per wave, planar
-    # scan list>, from the layout the library chose at upload (rt_debug_scan_layout)
+    # template arguments as rocprofv3 prints them: <noise textures compiled in, two LDS tile buffers per wave, scan mode
+    # (0 general lists, 1 with the planar list, 2 no scan: every sphere on the f64 list)>, from the layout the library
+    # chose at upload (rt_debug_scan_layout)
     b = lambda v: "true" if v else "false"
-    kernel = "render_kernel<%s, %s, %s>" % (b(layout["noise"]), b(layout["tile_buffers"] == 2), b(layout["planar_slots"] > 0))
+    kernel = "render_kernel<%s, %s, %d>" % (b(layout["noise"]), b(layout["tile_buffers"] == 2), layout.get("scan", 0))
     return {"bound": "valu", "kernel": kernel,
             "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": achieved / FP32_VALU_PEAK_TFLOPS, "flops_per_ray": model["flops_per_ray"],

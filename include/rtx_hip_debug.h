@@ -24,13 +24,19 @@ int rt_debug_set_scan_order(rt_ctx* ctx, int world_order);
  * identical. */
 int rt_debug_set_planar_list(rt_ctx* ctx, int on);
 
+/* on = 0: the next rt_upload_scene keeps the scan lists even for a scene of a handful of spheres, which by default sends
+ * all of its spheres to the per-ray f64 list and runs the render kernel variant without a scan (all three scan-slot
+ * counts of rt_debug_scan_layout are then 0); on != 0 restores the default.  Results are identical up to the fp32
+ * rounding of the hit record's inputs (both decide hits in f64). */
+int rt_debug_set_direct(rt_ctx* ctx, int on);
+
 /* n = 1 or 2: the next rt_upload_scene gives every wave that many tile buffers in LDS (2: the in-flight paths of a
  * finished work unit keep adding into their tile's LDS sums; 1: they add straight into the global accumulators) when
  * that many fit; 0 restores the choice by LDS room and occupancy.  Results are identical. */
 int rt_debug_set_tile_buffers(rt_ctx* ctx, int n);
 
 /* How the last rt_upload_scene laid the world out for the scan, for tests and for bench.py's kernel name:
- * out = {big spheres, general static slots, planar slots, moving slots (each padded to whole chunks of 8),
+ * out = {big spheres, general static slots, planar slots, moving slots (each padded to whole chunks of 16),
  *        planar axis (0/1/2, -1 without a planar list), bit mask of the axes some moving sphere moves along (bit 0 =
  *        x; 2 = y only: the instantiation without the x and z interpolation; 0 without moving spheres),
  *        tile buffers per wave, noise variant (0/1)}. */

@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
     "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers", "rt_debug_set_planar_list",
-    "rt_debug_scan_layout",
+    "rt_debug_scan_layout", "rt_debug_set_direct",
 ]
 
 _lib = None
@@ -187,6 +187,8 @@ def load() -> C.CDLL:
     lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
     lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
     lib.rt_debug_set_tile_buffers.argtypes = [vp, C.c_int]
+    if hasattr(lib, "rt_debug_set_direct"):
+        lib.rt_debug_set_direct.argtypes = [vp, C.c_int]
     if hasattr(lib, "rt_debug_set_planar_list"):  # (absent from older builds that tools/ab*.sh compare against)
         lib.rt_debug_set_planar_list.argtypes = [vp, C.c_int]
         lib.rt_debug_scan_layout.argtypes = [vp, C.POINTER(C.c_int32 * 8)]
@@ -444,12 +446,20 @@ class Context:
         in the general one, from the next upload on."""
         self._check(self.lib.rt_debug_set_planar_list(self._h, 1 if on else 0))
 
+    def debug_set_direct(self, on: bool = True):
+        """include/rtx_hip_debug.h: scenes of a handful of spheres entirely on the f64 list and rendered by the kernel
+        variant without a scan (default), or laid out like any other scene, from the next upload on."""
+        self._check(self.lib.rt_debug_set_direct(self._h, 1 if on else 0))
+
     def debug_scan_layout(self) -> dict:
-        """include/rtx_hip_debug.h: how the last upload laid the world out for the scan."""
+        """include/rtx_hip_debug.h: how the last upload laid the world out for the scan.  `scan` is the render
+        kernel's third template argument: 0 general lists, 1 with the planar list, 2 no scan lists at all."""
         out = (C.c_int32 * 8)()
         self._check(self.lib.rt_debug_scan_layout(self._h, C.byref(out)))
         keys = ("n_big", "static_slots", "planar_slots", "moving_slots", "planar_axis", "moving_axes", "tile_buffers", "noise")
-        return dict(zip(keys, (int(v) for v in out)))
+        d = dict(zip(keys, (int(v) for v in out)))
+        d["scan"] = 1 if d["planar_slots"] > 0 else 2 if d["static_slots"] + d["moving_slots"] == 0 else 0
+        return d
 
     def debug_set_tile_buffers(self, n: int = 0):
         """include/rtx_hip_debug.h: LDS tile buffers per wave from the next upload on (0 = chosen by the library)."""

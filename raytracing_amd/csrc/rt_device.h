@@ -21,6 +21,13 @@
 
 #include "../../include/rtx_hip.h"
 
+// Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
+#ifdef RT_CENSUS
+#define RT_MARK(name) asm volatile("; RT_MARK " name)
+#else
+#define RT_MARK(name)
+#endif
+
 namespace rtd {
 
 constexpr int kChunk = 16;          // scan lists are padded to a multiple of this (4 groups: one s_load_dwordx16 of bounds)
@@ -132,7 +139,6 @@ static_assert(sizeof(ShadeRec) == 48, "ShadeRec layout");
 struct DevScene {
     ScanLists lists;
     const int32_t* scan_id;  // scan slot (static slots first, then planar, then moving) -> sphere id
-    const int32_t* id_slot;  // sphere id -> its scan slot, -1 for a big sphere
     // spheres too large for the fp32 scan (|c|,r >> 1: e.g. the r = 1000 ground): f64 test
     const int32_t* big_id;
     const BigSphere* big;  // n_big records, in big_id order
@@ -394,7 +400,7 @@ struct Floor {
 };
 // The root: "near root if it is in range, else the far root" (shape.rs:53-61) with the range start folded into
 // o': as unsigned bit patterns a negative float loses to any non-negative one, so the root taken is
-// umin(bits(b - s), bits(b + s)).
+// umin(bits(b - s), bits(b + s)) -- as take_root refines it.
 // `second` is the runner-up KEY (no slot): the smallest key among the candidates that did not become `best`
 // (v_med3_u32 keeps best <= second).  hit_end compares it with the exact (f64) depth of the accepted nominee: when
 // some other candidate's key does not lie safely beyond it, the ray is traced again from that nominee on and the next
@@ -403,8 +409,18 @@ template <bool kFloor>
 __device__ __forceinline__ void take_root(float b, float disc, int slot, int lo, int ls, uint32_t& best, uint32_t& second,
                                           int& idx) {
     const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
-    const uint32_t k1 = __float_as_uint(b - s), k2 = __float_as_uint(b + s);
-    uint32_t key = min(k1, k2);
+    // A key must be a LOWER bound of the exact depth (hit_end stops looking once the next key exceeds the exact best).
+    // The near root b - s is one (the inflated direction and the widened radius both lower it); the far root b + s is
+    // not -- the widened radius raises it, by far more than the keys' error bound when the ray runs tangent just inside
+    // the surface -- so a ray that starts inside a sphere (near root negative, far root ahead) gets the key +0 for it:
+    // the median of (b - s, b + s, z) with z = disc * 0 (+0, or -0 when disc < 0) is the near root when that is ahead,
+    // +0 when only the far root is, and the (negative: loses as an unsigned pattern) far root when both are behind;
+    // for disc < 0 the two roots are NaNs, v_med3_f32 then returns the minimum of its non-NaN operands: -0, which loses.
+#ifdef RT_X_OLDKEY
+    uint32_t key = min(__float_as_uint(b - s), __float_as_uint(b + s));
+#else
+    uint32_t key = __float_as_uint(__builtin_amdgcn_fmed3f(b - s, b + s, disc * 0.0f));
+#endif
     if (kFloor) key = ((int)key > lo - (slot > ls ? 1 : 0)) ? key : 0xFFFFFFFFu;  // at or before the floor: decided already
 #ifndef RT_X_NOSECOND
     second = max(min(key, best), min(max(key, best), second));  // v_med3_u32
@@ -652,7 +668,8 @@ __device__ __forceinline__ double sqrt_f64(double x) {
     return x == 0.0 ? 0.0 : g;  // rsq(0) = inf
 }
 // centre at the ray's time, shape.rs:96-98 (dc = 0 for a static sphere), from one 16-byte record {c0, .} (+ {dc, .})
-__device__ __forceinline__ void sphere_centre_f64(const DevScene& S, const float4* c0, const float4* dc, int i, float time,
+template <class SceneT>
+__device__ __forceinline__ void sphere_centre_f64(const SceneT& S, const float4* c0, const float4* dc, int i, float time,
                                                   double& cx, double& cy, double& cz, float& w) {
     const v4f a = *reinterpret_cast<const v4f*>(c0 + i);
     cx = (double)a.x; cy = (double)a.y; cz = (double)a.z; w = a.w;
@@ -712,8 +729,11 @@ constexpr float kScanInflate = 1.0f + 8.0f / 16777216.0f;
 // needs no per-ray term: ScanLists::key_eps0 = kKeyEps0 * C is a scene constant.
 constexpr float kKeyRel = 128.0f / 16777216.0f;
 constexpr float kKeyEps0 = 64.0f / 16777216.0f;
-// The scan does not start at t_min but kStartShift of it EARLIER: a root just above t_min (which the reference takes,
-// shape.rs:54 `t_min <= t`) must not come out of the fp32 arithmetic with a negative key and be lost.  Roots inside the
+// The scan does not start at t_min but EARLIER, by kStartShift of t_min plus, along the ray, the keys' absolute
+// error near the scene (half of ScanLists::key_eps0; a distance, so key_eps0 / 2|d| in units of t): a root at or just above t_min
+// (which the reference takes, shape.rs:54 `t_min <= t`) must not come out of the fp32 arithmetic with a negative key
+// and be lost.  The distance term is what protects rays with a tiny direction (a Lambertian n + S that nearly
+// cancels: |d| ~ 1e-3 stretches t_min = 1e-3 to a distance of 1e-6, below the keys' resolution).  Roots inside the
 // shifted-in sliver are nominated, rejected by the f64 test (which uses the true t_min) and passed over (kRetry).
 constexpr float kStartShift = 1.0f / 32.0f;
 __host__ __device__ __forceinline__ float scan_start(float t_min) { return t_min - t_min * kStartShift; }
@@ -725,10 +745,10 @@ struct HitConsts {
     double t_min, t_start;  // the reference's range start (main.rs:116) and where the scan starts
     double ox, oy, oz;      // ScanLists::ox, oy, oz
     float key_eps0;         // ScanLists::key_eps0
-    float pad;
+    float t_start_f;        // t_start as computed in fp32 (scan_start)
 };
 __host__ __device__ inline HitConsts make_hit_consts(const ScanLists& L, float t_min) {
-    return {(double)t_min, (double)scan_start(t_min), (double)L.ox, (double)L.oy, (double)L.oz, L.key_eps0, 0.0f};
+    return {(double)t_min, (double)scan_start(t_min), (double)L.ox, (double)L.oy, (double)L.oz, L.key_eps0, scan_start(t_min)};
 }
 __device__ __forceinline__ double dir_len2(const Ray& r) {
     return (double)r.d.x * (double)r.d.x + (double)r.d.y * (double)r.d.y + (double)r.d.z * (double)r.d.z;
@@ -737,63 +757,20 @@ __device__ __forceinline__ double dir_len2(const Ray& r) {
 // cannot be closer than that hit.
 __device__ __forceinline__ uint32_t hit_key(const HitWork& w, const HitConsts& C) {
     if (w.id_best < 0) return kInfBits;
-    const float tb = (float)(w.t_best - C.t_start) * w.key_scale;  // >= 0: t_best >= t_min > t_start
+    // distance from the scan's start: (t - t_start) |d| + the distance part of the shift (x (1 + 32 ulp): the
+    // inflation, squared, and the roundings of closest_begin's t_start - 2 key_eps0 / |d|)
+    const float tb = fmaf((float)(w.t_best - C.t_start), w.key_scale, C.key_eps0 * (0.5f + 16.0f / 16777216.0f));  // >= 0: t_best >= t_min > t_start
     return __float_as_uint(fmaf(tb, 1.0f + kKeyRel, C.key_eps0));
 }
-// HitRec::sphere == kRetry: the trace of this ray segment is NOT finished.  Either the scan's nominee was a false
-// positive of the conservative fp32 test, or it was accepted but another candidate's key (Hit2::second) lies below
-// its exact depth's bound, so that candidate must be decided in f64 too.  The ray is traced AGAIN with the nominee's
-// (key, slot) as the floor of the scan -- candidates at or before it are skipped -- and with the exact best so far
-// carried along, until no undecided candidate can be closer.  Near-ties are therefore ordered by f64 depths and exact
-// ties by world order, as the reference does; the fp32 keys only decide in which order candidates are looked at.
-// The record of an unfinished trace: sphere = kRetry, t = the floor's key bits, front = the floor's slot in its low
-// 16 bits and, above them, 1 + the scan slot of the best candidate accepted so far (0: none; a big sphere's hit is
-// found again by every pass).  Three registers, as many as a pass-over needed before there was anything to carry: the
-// carried candidate's depth is recomputed by the next pass (same inputs, same code: the same bits).
-constexpr int kRetry = -2;
-__device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
-__device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? (h.front & 0xFFFF) : 0x7FFFFFFF; }
-__device__ __forceinline__ void merge_carry(const DevScene& S, const Ray& r, const HitConsts& C, HitWork& w, const HitRec& h) {
-    const int cs = h.sphere == kRetry ? (h.front >> 16) - 1 : -1;
-    if (cs >= 0) {
-        const double inf = __longlong_as_double(0x7FF0000000000000ll);
-        double cx, cy, cz, t;
-        float rad;
-        sphere_centre_f64(S, S.slot_a, S.slot_dc, cs, r.time, cx, cy, cz, rad);
-        const int id = S.scan_id[cs];
-        if (sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, C.t_min, inf, t) &&
-            closer_hit(t, id, w.t_best, w.id_best)) {
-            w.t_best = t; w.id_best = id;
-        }
-    }
-}
-__device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, const HitConsts& C, HitWork& w, uint32_t best,
-                                          uint32_t second, int slot) {
-    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+// The hit record of the winner (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed; a miss is all zeros.
+template <class SceneT>
+__device__ __forceinline__ HitRec hit_record(const SceneT& S, const Ray& r, const HitWork& w) {
     HitRec h;
-    if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
-        const int id = S.scan_id[slot];
-        double cx, cy, cz, t;
-        float rad;
-        sphere_centre_f64(S, S.slot_a, S.slot_dc, slot, r.time, cx, cy, cz, rad);
-        if (id >= 0 && sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, C.t_min, inf, t) &&
-            closer_hit(t, id, w.t_best, w.id_best)) {
-            w.t_best = t; w.id_best = id;
-        }
-        // every candidate not decided yet has a key >= second: final unless that may still be closer than the best
-        if (second < hit_key(w, C)) {
-            const int carried = w.id_best >= 0 ? S.id_slot[w.id_best] : -1;  // -1: none, or a big sphere
-            h.sphere = kRetry; h.front = slot | ((carried + 1) << 16); h.t = __uint_as_float(best);
-            h.p = {0, 0, 0}; h.n = {0, 0, 0};
-            return h;
-        }
-    }
     h.sphere = w.id_best;
     if (w.id_best < 0) {
         h.front = 0; h.t = 0.0f; h.p = {0, 0, 0}; h.n = {0, 0, 0};
         return h;
     }
-    // hit record (shape.rs:45-50, hit.rs:45-61) in f64, then narrowed
     const int id = w.id_best;
     double cx, cy, cz;
     float inv_rad;  // 1/r rounded to fp32: |n| = 1 +- 6e-8
@@ -811,7 +788,98 @@ __device__ __forceinline__ HitRec hit_end(const DevScene& S, const Ray& r, const
     h.n = {(float)nx, (float)ny, (float)nz};
     return h;
 }
+// HitRec::sphere == kRetry: the trace of this ray segment is NOT finished.  Either the scan's nominee was a false
+// positive of the conservative fp32 test, or it was accepted but another candidate's key (Hit2::second) lies below
+// its exact depth's bound, so that candidate must be decided in f64 too.  The ray is traced AGAIN with the nominee's
+// (key, slot) as the floor of the scan -- candidates at or before it are skipped -- and with the exact best so far
+// carried along, until no undecided candidate can be closer.  Near-ties are therefore ordered by f64 depths and exact
+// ties by world order, as the reference does; the fp32 keys only decide in which order candidates are looked at.
+// The record of an unfinished trace: sphere = kRetry, t = the floor's key bits, front = the floor's slot, and the exact
+// best so far (a scan candidate accepted by an earlier pass; a big sphere's hit is found again by every pass anyway) in
+// the fields a finished record uses for the hit point: p.x = its sphere id (bits; -1: none), p.y / p.z = its f64 depth.
+constexpr int kRetry = -2;
+__device__ __forceinline__ int retry_key(const HitRec& h) { return h.sphere == kRetry ? __float_as_int(h.t) : -1; }
+__device__ __forceinline__ int retry_slot(const HitRec& h) { return h.sphere == kRetry ? h.front : 0x7FFFFFFF; }
+__device__ __forceinline__ void merge_carry(HitWork& w, const HitRec& h) {
+    if (h.sphere == kRetry) {
+        const int id = __float_as_int(h.p.x);
+        const double t = __hiloint2double(__float_as_int(h.p.z), __float_as_int(h.p.y));
+        if (id >= 0 && closer_hit(t, id, w.t_best, w.id_best)) { w.t_best = t; w.id_best = id; }
+    }
+}
+template <class SceneT>
+__device__ __forceinline__ HitRec hit_end(const SceneT& S, const Ray& r, const HitConsts& C, HitWork& w, uint32_t best,
+                                          uint32_t second, int slot) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    HitRec h;
+    if (slot >= 0 && best < kInfBits) {  // the scan's nominee, decided in f64
+        const int id = S.scan_id[slot];
+        double cx, cy, cz, t;
+        float rad;
+        sphere_centre_f64(S, S.slot_a, S.slot_dc, slot, r.time, cx, cy, cz, rad);
+        if (id >= 0 && sphere_roots_f64(cx, cy, cz, (double)rad * (double)rad, r, dir_len2(r), w.inv_a, C.t_min, inf, t) &&
+            closer_hit(t, id, w.t_best, w.id_best)) {
+            w.t_best = t; w.id_best = id;
+        }
+        // every candidate not decided yet has a key >= second: final unless that may still be closer than the best
+        if (second < hit_key(w, C)) {
+            h.sphere = kRetry; h.front = slot; h.t = __uint_as_float(best);
+            h.p = {__int_as_float(w.id_best), __int_as_float(__double2loint(w.t_best)), __int_as_float(__double2hiint(w.t_best))};
+            h.n = {0, 0, 0};
+            return h;
+        }
+    }
+    return hit_record(S, r, w);
+}
 
+// The spheres of the f64 list against the two rays of a lane, world order: one scalar load per sphere serves both.
+// `tie_by_id`: a hit of a LATER sphere may already be in w (carried over by a retrace), then (t, id) decides.
+template <class SceneT>
+__device__ __forceinline__ void big_spheres_f64(const SceneT& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                                const HitConsts& C, bool tie_by_id, double aa, double ab, HitWork& wa,
+                                                HitWork& wb) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    typedef double d8 __attribute__((ext_vector_type(8)));
+    const RT_AS4 d8* big = (const RT_AS4 d8*)(uintptr_t)S.big;
+    const RT_AS4 int32_t* big_id = (const RT_AS4 int32_t*)(uintptr_t)S.big_id;
+    const int n_big = S.n_big;
+    const bool moving = S.any_moving;
+    for (int k = 0; k < n_big; ++k) {
+        const d8 B = big[k];  // {cx, cy, cz, r2, dcx, dcy, dcz, inv_r}
+        const int id = big_id[k];
+        auto test = [&](const Ray& r, double a, HitWork& w) {
+            double cx = B[0], cy = B[1], cz = B[2], t;
+            if (moving) { const double tm = (double)r.time; cx += tm * B[4]; cy += tm * B[5]; cz += tm * B[6]; }
+            // world order: strictly closer (hit.rs:100-110)
+            if (sphere_roots_f64(cx, cy, cz, B[3], r, a, w.inv_a, C.t_min, inf, t) &&
+                (t < w.t_best || (tie_by_id && closer_hit(t, id, w.t_best, w.id_best)))) {
+                w.t_best = t; w.id_best = id;
+            }
+        };
+        if (do_a) test(ra, aa, wa);
+        if (do_b) test(rb, ab, wb);
+    }
+}
+// A scene WITHOUT scan lists (upload sends every sphere of a scene of at most kDirectMax spheres besides the big
+// ones to the f64 list: the reference's noise scenes are a ground and one ball): HitList::hit is the f64 loop and the
+// hit record, nothing else -- no scan frame, no nomination, no decision, no retrace.
+constexpr int kDirectMax = 4;
+template <class SceneT>
+__device__ __forceinline__ void closest_direct(const SceneT& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+                                               const HitConsts& C, HitRec& ha, HitRec& hb) {
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    HitWork wa, wb;
+    wa.id_best = wb.id_best = -1;
+    wa.t_best = wb.t_best = inf;
+    wa.key_scale = wb.key_scale = 0.0f;
+    const double aa = dir_len2(ra), ab = dir_len2(rb);
+    wa.inv_a = rcp_f64(aa);
+    wb.inv_a = rcp_f64(ab);
+    big_spheres_f64(S, ra, rb, do_a, do_b, C, false, aa, ab, wa, wb);
+    ha.sphere = hb.sphere = -1;
+    if (do_a) ha = hit_record(S, ra, wa);
+    if (do_b) hb = hit_record(S, rb, wb);
+}
 // HitList::hit(ray, t_min..inf) (hit.rs:100-110) for the TWO rays of a lane: closest hit over the whole world, in
 // three steps so that a caller can re-read its scene arguments between them (render_kernel):
 //   closest_begin: f64 big-sphere pass + the scan frame;  scan_spheres;  closest_end: f64 decision + hit records.
@@ -833,8 +901,8 @@ __device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Floor&
 }
 // prev_a / prev_b: the rays' records of the previous trace; `carry` (wave-uniform) says whether any of them may be a
 // kRetry record whose exact best so far has to be taken over (passes without a retracing lane skip that code).
-template <bool kPlanar>
-__device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+template <bool kPlanar, class SceneT>
+__device__ __forceinline__ void closest_begin(const SceneT& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                               const HitConsts& C, bool carry, const HitRec& prev_a, const HitRec& prev_b,
                                               Hit2& x) {
     const double inf = __longlong_as_double(0x7FF0000000000000ll);
@@ -846,30 +914,12 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     x.wa.inv_a = rcp_f64(aa);
     x.wb.inv_a = rcp_f64(ab);
     if (carry) {  // a retracing lane's best candidate so far, decided again
-        if (do_a) merge_carry(S, ra, C, x.wa, prev_a);
-        if (do_b) merge_carry(S, rb, C, x.wb, prev_b);
+        RT_MARK("carry");
+        if (do_a) merge_carry(x.wa, prev_a);
+        if (do_b) merge_carry(x.wb, prev_b);
     }
-    {  // big spheres, f64: one scalar load per sphere serves both rays
-        typedef double d8 __attribute__((ext_vector_type(8)));
-        const RT_AS4 d8* big = (const RT_AS4 d8*)(uintptr_t)S.big;
-        const RT_AS4 int32_t* big_id = (const RT_AS4 int32_t*)(uintptr_t)S.big_id;
-        for (int k = 0; k < S.n_big; ++k) {
-            const d8 B = big[k];  // {cx, cy, cz, r2, dcx, dcy, dcz, inv_r}
-            const int id = big_id[k];
-            const bool moving = S.any_moving;
-            auto test = [&](const Ray& r, double a, HitWork& w) {
-                double cx = B[0], cy = B[1], cz = B[2], t;
-                if (moving) { const double tm = (double)r.time; cx += tm * B[4]; cy += tm * B[5]; cz += tm * B[6]; }
-                // world order: strictly closer, unless a carried hit of a LATER sphere is in w (then (t, id) decides)
-                if (sphere_roots_f64(cx, cy, cz, B[3], r, a, w.inv_a, C.t_min, inf, t) &&
-                    (t < w.t_best || (carry && closer_hit(t, id, w.t_best, w.id_best)))) {
-                    w.t_best = t; w.id_best = id;
-                }
-            };
-            if (do_a) test(ra, aa, x.wa);
-            if (do_b) test(rb, ab, x.wb);
-        }
-    }
+    RT_MARK("begin");
+    big_spheres_f64(S, ra, rb, do_a, do_b, C, carry, aa, ab, x.wa, x.wb);
     const float la2 = (float)aa, lb2 = (float)ab;
     const float inv_la = fast_rsq(la2) * kScanInflate, inv_lb = fast_rsq(lb2) * kScanInflate;
     x.wa.key_scale = la2 * inv_la;
@@ -878,12 +928,17 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     p.dx = f2{ra.d.x * inv_la, rb.d.x * inv_lb};
     p.dy = f2{ra.d.y * inv_la, rb.d.y * inv_lb};
     p.dz = f2{ra.d.z * inv_la, rb.d.z * inv_lb};
-    // o' = o + t_start*d - origin in f64, rounded once: its error is an ulp of the SCAN-FRAME coordinate
-    const ScanLists& L = S.lists;
-    auto frame = [&](float o, float d, double org) { return (float)(((double)o + C.t_start * (double)d) - org); };
-    f2 ox = f2{frame(ra.o.x, ra.d.x, C.ox), frame(rb.o.x, rb.d.x, C.ox)};
-    f2 oy = f2{frame(ra.o.y, ra.d.y, C.oy), frame(rb.o.y, rb.d.y, C.oy)};
-    f2 oz = f2{frame(ra.o.z, ra.d.z, C.oz), frame(rb.o.z, rb.d.z, C.oz)};
+    // o' = o + t_start_ray*d - origin in f64, rounded once: its error is an ulp of the SCAN-FRAME coordinate
+    const auto& L = S.lists;
+#ifdef RT_X_NOABSSHIFT
+    const double tsa = C.t_start, tsb = C.t_start;
+#else
+    const double tsa = (double)fmaf(-0.5f * C.key_eps0, inv_la, C.t_start_f), tsb = (double)fmaf(-0.5f * C.key_eps0, inv_lb, C.t_start_f);
+#endif
+    auto frame = [&](float o, float d, double ts, double org) { return (float)(((double)o + ts * (double)d) - org); };
+    f2 ox = f2{frame(ra.o.x, ra.d.x, tsa, C.ox), frame(rb.o.x, rb.d.x, tsb, C.ox)};
+    f2 oy = f2{frame(ra.o.y, ra.d.y, tsa, C.oy), frame(rb.o.y, rb.d.y, tsb, C.oy)};
+    f2 oz = f2{frame(ra.o.z, ra.d.z, tsa, C.oz), frame(rb.o.z, rb.d.z, tsb, C.oz)};
     p.time = f2{ra.time, rb.time};
     // a dead ray rides through the packed scan: park it (d = 0, far origin => disc = -|oc|^2 - ... < 0 for every
     // sphere, in either form) so it never sends its wave into a root-extraction group
@@ -906,7 +961,8 @@ __device__ __forceinline__ void closest_begin(const DevScene& S, const Ray& ra, 
     }
     x.slot_a = x.slot_b = -1;
 }
-__device__ __forceinline__ void closest_end(const DevScene& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
+template <class SceneT>
+__device__ __forceinline__ void closest_end(const SceneT& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                             const HitConsts& C, Hit2& x, HitRec& ha, HitRec& hb) {
     ha.sphere = -1;
     hb.sphere = -1;
@@ -919,6 +975,10 @@ __device__ __forceinline__ void closest_hit2(const DevScene& S, const Ray& ra, c
     ha.sphere = hb.sphere = -1;
     Floor fl = {-1, -1, 0x7FFFFFFF, 0x7FFFFFFF};
     const HitConsts C = make_hit_consts(S.lists, t_min);
+    if (S.lists.ns_pad + S.lists.np_pad + S.lists.nm_pad == 0) {  // (wave-uniform) the render kernel's direct variant
+        closest_direct(S, ra, rb, do_a, do_b, C, ha, hb);
+        return;
+    }
     while (__ballot(do_a || do_b) != 0ull) {  // wave-uniform: every lane runs the packed scan together
         Hit2 x;
         HitRec na, nb;
@@ -1011,7 +1071,8 @@ __device__ __forceinline__ f2 noise_eval2(const TexT& T, const FusedNoise* lds_f
 // The noise values of a lane's two texture requests (tex < 0: none).  Lanes of a wave may ask for different
 // textures: the loop runs once per DISTINCT texture of the wave (every reference scene has one), with that
 // texture's descriptor read through the scalar cache.
-__device__ __forceinline__ void noise_pair(const DevScene& S, const FusedNoise* lds_fused, int tex0, int tex1, f3 p0,
+template <class SceneT>
+__device__ __forceinline__ void noise_pair(const SceneT& S, const FusedNoise* lds_fused, int tex0, int tex1, f3 p0,
                                            f3 p1, float& v0, float& v1) {
     typedef const RT_AS4 DevTexture* TexPtr;
     const TexPtr texs = (TexPtr)(uintptr_t)S.texs;
@@ -1078,8 +1139,8 @@ __device__ __forceinline__ float schlick(float cosv, float eta) {  // material.r
 // caller evaluates the noise at r.o (= the hit point) for both path slots together (noise_pair) and multiplies.
 // kNoise = false compiles that out: the render kernel is instantiated both ways and the scenes without a noise
 // texture (upload knows) run the variant whose register budget is not set by the noise code.
-template <bool kNoise = true>
-__device__ inline f3 scatter(const DevScene& S, const HitRec& h, Ray& r, float u0, float u1, int& noise_tex) {
+template <bool kNoise = true, class SceneT>
+__device__ inline f3 scatter(const SceneT& S, const HitRec& h, Ray& r, float u0, float u1, int& noise_tex) {
     const ShadeRec m = S.shade[h.sphere];
     const f3 ud = normalize(r.d);
     const float dn = dot(ud, h.n);

@@ -37,6 +37,11 @@ constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes
 // classified the same way (round 1 used r >= 50 or |c| >= 500 in absolute units).
 constexpr float kBigRatio = 32.0f;
 constexpr size_t kMaxBig = 64;
+#ifdef RT_X_NOSLACK
+constexpr double kDirectSlack = 0.0;
+#else
+constexpr double kDirectSlack = 16.0 / 16777216.0;
+#endif  // see nr2_scan in rt_upload_scene
 
 // Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
 // radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
@@ -96,14 +101,11 @@ __host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (si
                            // (a build that takes 174 VGPRs, nothing spilled) measure +24 % on configs[1] and +23 % on
                            // Random: the third wave is needed to keep the VALU pipes busy, a fourth is not
 #endif
-// Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
-#ifdef RT_CENSUS
-#define RT_MARK(name) asm volatile("; RT_MARK " name)
-#else
-#define RT_MARK(name)
-#endif
-template <bool kNoise, bool kTwoBufs, bool kPlanar>
+// kScan: what HitList::hit walks besides the f64 list -- 0: the general scan lists, 1: those and the planar list,
+// 2: nothing (a scene of a few spheres, all of them on the f64 list: closest_direct)
+template <bool kNoise, bool kTwoBufs, int kScan>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
+    constexpr bool kPlanar = kScan == 1, kDirect = kScan == 2;
     // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
     // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
     // (refill) and the scan-list fields (scan) are re-read from the kernarg segment (constant address space =>
@@ -145,11 +147,14 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         // the tile's 3*npix sums are row-major in LDS; lanes take consecutive elements so that the atomics of one
         // instruction fall on consecutive addresses of (at most three) image rows
         const uint32_t row = fw * 3, n = fnpix * 3;
+        const ArgsPtr K = launder(K0);
+        unsigned long long* const g_accum = K->accum;
+        const uint32_t img_w = K->W;
         for (uint32_t e = lane; e < n; e += 64) {
             const unsigned long long q = acc[off + e];
             if (q) {
                 const uint32_t ly = e / row, rem = e - ly * row;
-                atomicAdd(A.accum + ((size_t)(fy0 + ly) * A.W + fx0) * 3 + rem, q);
+                atomicAdd(g_accum + ((size_t)(fy0 + ly) * img_w + fx0) * 3 + rem, q);
                 acc[off + e] = 0;
             }
         }
@@ -178,19 +183,20 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             if (ps[1].acc_idx - old_off < kTileAcc) ps[1].acc_idx = kOrphan;
             if (lane == 0) { prev_geo[0] = tx0; prev_geo[1] = ty0; prev_geo[2] = tw; prev_geo[3] = npix; }
             cur_off = old_off;  // the buffer just emptied takes the next tile
+            const ArgsPtr K = launder(K0);  // the launch plan: read here (once per ~65 passes), not held in SGPRs
             uint32_t u = 0;
-            if (lane == 0) u = atomicAdd(A.unit_counter, 1u);
+            if (lane == 0) u = atomicAdd(K->unit_counter, 1u);
             u = __builtin_amdgcn_readfirstlane(u);
             next = 0;
-            if (u < A.n_units) {
-                const uint32_t tile = u % A.n_tiles, chunk = u / A.n_tiles;
-                tx0 = (tile % A.tiles_x) * kTile;
-                ty0 = (tile / A.tiles_x) * kTile;
-                tw = min((uint32_t)kTile, A.W - tx0);
-                npix = tw * min((uint32_t)kTile, A.H - ty0);
-                const bool big = chunk < A.n_a;
-                s_lo = big ? chunk * A.spp_a : A.n_a * A.spp_a + (chunk - A.n_a) * A.spp_b;
-                total = npix * (big ? A.spp_a : min(A.spp_b, A.spp_count - s_lo));
+            if (u < K->n_units) {
+                const uint32_t tile = u % K->n_tiles, chunk = u / K->n_tiles;
+                tx0 = (tile % K->tiles_x) * kTile;
+                ty0 = (tile / K->tiles_x) * kTile;
+                tw = min((uint32_t)kTile, K->W - tx0);
+                npix = tw * min((uint32_t)kTile, K->H - ty0);
+                const bool big = chunk < K->n_a;
+                s_lo = big ? chunk * K->spp_a : K->n_a * K->spp_a + (chunk - K->n_a) * K->spp_b;
+                total = npix * (big ? K->spp_a : min(K->spp_b, K->spp_count - s_lo));
             } else {
                 more = false;
                 npix = 0;
@@ -208,7 +214,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             // a slot whose nominee the f64 test rejected in the previous pass (h[s].sphere == kRetry) keeps its ray
             // and is traced again below with that nominee's key as the scan floor: no scatter, no new random numbers
             RT_MARK("refill");
-            const bool retry = P.alive && h[s].sphere == kRetry;
+            const bool retry = !kDirect && P.alive && h[s].sphere == kRetry;
             const unsigned long long need = __ballot(!P.alive);
             bool fresh = false;
             uint32_t x = 0, y = 0;
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
                 } else {  // the path hit h[s] in the previous pass and goes on (main.rs:117-125)
                     RT_MARK("scatter");
-                    const f3 albedo = scatter<kNoise>(A.S, h[s], P.ray, u01(r[0]), u01(r[1]), noise_tex[s]);
+                    const f3 albedo = scatter<kNoise>(K->S, h[s], P.ray, u01(r[0]), u01(r[1]), noise_tex[s]);
                     P.thr = P.thr * albedo;  // main.rs:118
                     ++P.depth;
                 }
@@ -266,7 +272,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         RT_MARK("noise");
         if (kNoise) {  // the two slots' noise textures in one packed evaluation at the hit points (= the new ray origins)
             float v0 = 1.0f, v1 = 1.0f;
-            noise_pair(A.S, L.fused, noise_tex[0], noise_tex[1], ps[0].ray.o, ps[1].ray.o, v0, v1);
+            noise_pair(launder(K0)->S, L.fused, noise_tex[0], noise_tex[1], ps[0].ray.o, ps[1].ray.o, v0, v1);
             ps[0].thr = ps[0].thr * v0;  // colour = white * value (material.rs:369-373, :529-533)
             ps[1].thr = ps[1].thr * v1;
         }
@@ -277,6 +283,12 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         }
 
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
+        if constexpr (kDirect) {
+            RT_MARK("begin");
+            const ArgsPtr K = launder(K0);
+            const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, K->hc.t_start_f};
+            closest_direct(K->S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, h[0], h[1]);
+        } else
         {
             Hit2 x;
             const bool retry_a = ps[0].alive && h[0].sphere == kRetry, retry_b = ps[1].alive && h[1].sphere == kRetry;
@@ -286,8 +298,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             RT_MARK("begin");
             {
                 const ArgsPtr K = launder(K0);
-                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, 0.0f};
-                closest_begin<kPlanar>(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, any_retry, h[0], h[1], x);
+                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, K->hc.t_start_f};
+                closest_begin<kPlanar>(K->S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, any_retry, h[0], h[1], x);
             }
             {
                 const ArgsPtr K = launder(K0);
@@ -318,8 +330,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             RT_MARK("end");
             {
                 const ArgsPtr K = launder(K0);
-                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, 0.0f};
-                closest_end(A.S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, x, h[0], h[1]);
+                const HitConsts C = {K->hc.t_min, K->hc.t_start, K->hc.ox, K->hc.oy, K->hc.oz, K->hc.key_eps0, K->hc.t_start_f};
+                closest_end(K->S, ps[0].ray, ps[1].ray, ps[0].alive, ps[1].alive, C, x, h[0], h[1]);
             }
 #ifdef RT_STATS
             {  // g_dbg[7]: ray segments that end this pass unfinished (kRetry: passed over or carried on)
@@ -335,7 +347,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
         for (int s = 0; s < 2; ++s) {
             PathState& P = ps[s];
             RT_MARK("terminate");
-            if (P.alive && h[s].sphere != kRetry) {  // (a rejected nominee: same ray segment again next pass)
+            const ArgsPtr K = launder(K0);
+            if (P.alive && (kDirect || h[s].sphere != kRetry)) {  // (an unfinished trace: same ray segment again next pass)
                 ++n_rays;
                 if (h[s].sphere < 0) {
                     P.alive = false;
@@ -349,11 +362,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                         const uint32_t whole = (uint32_t)v;
                         const unsigned long long q = ((unsigned long long)whole << 32) | (uint32_t)((v - (float)whole) * kTwoPow32);
                         if (q) {
-                            if (P.acc_idx == kOrphan) atomicAdd(A.accum + (size_t)P.pix * 3 + k, q);
+                            if (P.acc_idx == kOrphan) atomicAdd(K->accum + (size_t)P.pix * 3 + k, q);
                             else atomicAdd(&acc[P.acc_idx + k], q);
                         }
                     }
-                } else if (P.depth + 1 == A.max_depth) {
+                } else if (P.depth + 1 == K->max_depth) {
                     P.alive = false;
                 }
             }
@@ -366,16 +379,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
     // ray-segment counter: wave reduction, one atomic per wave
     for (int off = 32; off > 0; off >>= 1) n_rays += __shfl_down(n_rays, off, 64);
-    if (lane == 0 && n_rays) atomicAdd(A.rays, n_rays);
+    if (lane == 0 && n_rays) atomicAdd(launder(K0)->rays, n_rays);
 }
 
 // the variant a scene runs: with or without the noise textures compiled in, two tile buffers per wave or one
 typedef void (*RenderKernel)(const RenderArgs);
 template <bool kNoise, bool kTwoBufs>
-static RenderKernel render_variant2(bool planar) { return planar ? render_kernel<kNoise, kTwoBufs, true> : render_kernel<kNoise, kTwoBufs, false>; }
-static RenderKernel render_variant(bool noise, bool two_bufs, bool planar) {
-    return noise ? (two_bufs ? render_variant2<true, true>(planar) : render_variant2<true, false>(planar))
-                 : (two_bufs ? render_variant2<false, true>(planar) : render_variant2<false, false>(planar));
+static RenderKernel render_variant2(int scan) {
+    return scan == 2 ? render_kernel<kNoise, kTwoBufs, 2> : scan == 1 ? render_kernel<kNoise, kTwoBufs, 1> : render_kernel<kNoise, kTwoBufs, 0>;
+}
+static RenderKernel render_variant(bool noise, bool two_bufs, int scan) {
+    return noise ? (two_bufs ? render_variant2<true, true>(scan) : render_variant2<true, false>(scan))
+                 : (two_bufs ? render_variant2<false, true>(scan) : render_variant2<false, false>(scan));
 }
 
 __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, float* __restrict__ out, size_t n,
@@ -545,7 +560,8 @@ struct rt_ctx {
     int32_t dbg_tail_span = -1;
     bool dbg_world_order = false;
     bool dbg_no_planar = false;
-    bool has_planar = false;  // the scene has a planar list: the render kernel variant with its walk
+    int scan_mode = 0;        // render_kernel's kScan for the uploaded scene: 0 general lists, 1 + planar list, 2 no lists
+    bool dbg_no_direct = false;
     int dbg_tile_bufs = 0;
 };
 
@@ -757,6 +773,13 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         }
         for (uint32_t i : cand) is_big[i] = 1;
     }
+    // A scene that leaves at most kDirectMax spheres for the scan (the reference's noise scenes: a ground and one ball)
+    // does without it: every sphere goes to the f64 list, which costs ~60 VALU per sphere and pass, where the scan's
+    // frame, walk, nomination and decision cost ~300 before the first sphere (render_kernel's kScan = 2).
+    {
+        const size_t n_small = (size_t)std::count(is_big.begin(), is_big.end(), 0);
+        if (!c->dbg_no_direct && n_small <= (size_t)kDirectMax && s->n_spheres <= kMaxBig) std::fill(is_big.begin(), is_big.end(), 1);
+    }
     // The scan frame: centres relative to the middle of the small spheres' bounding box (motion included), so that
     // the expanded static test (rt_device.h) cancels numbers no larger than the scene itself.
     double lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
@@ -812,6 +835,19 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     std::vector<float4> plan;
     std::vector<float> plan_nr2;
     std::vector<int32_t> plan_id;
+    for (uint32_t i = 0; i < s->n_spheres; ++i) {  // how far from the frame's origin a scan sphere reaches, over its whole motion
+        if (is_big[i]) continue;
+        const double cx = (double)s->c0x[i] - org[0], cy = (double)s->c0y[i] - org[1], cz = (double)s->c0z[i] - org[2];
+        const double ex = cx + s->dcx[i], ey = cy + s->dcy[i], ez = cz + s->dcz[i];
+        reach = std::max(reach, std::max(std::sqrt(cx * cx + cy * cy + cz * cz), std::sqrt(ex * ex + ey * ey + ez * ez)) + (double)s->radius[i]);
+    }
+    // -r^2 as the DIRECT form of the scan's test reads it (rt_device.h: terms_static_direct, terms_moving), widened so
+    // that the test stays conservative where the direction's inflation (kScanInflate, 16 ulp of b^2) cannot help: a
+    // ray that starts next to the sphere and runs tangent to it has b ~ 0, and disc = b^2 - (|oc|^2 - r^2) is then
+    // decided by the roundings of |oc|^2 (a few ulp of r^2) and of centre and origin into the scan frame (2 ulp of
+    // the frame coordinates per component of oc: 8 ulp of r * reach in |oc_perp|^2).  16 ulp of each, twice the bound.
+    // The f64 decision uses the true radius (slot_a); all this costs is a slightly wider band of false nominations.
+    auto nr2_scan = [&](double r) { return (float)-(r * r * (1.0 + kDirectSlack) + kDirectSlack * r * reach); };
     for (uint32_t i = 0; i < s->n_spheres; ++i) {
         const double r = s->radius[i];
         const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
@@ -819,7 +855,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         if (is_big[i]) {
             big_id.push_back((int32_t)i);  // world order (first wins an exact tie, hit.rs:100-110)
         } else if (moving) {
-            mov_a.push_back(make_float4((float)cx, (float)cy, (float)cz, (float)-(r * r)));
+            mov_a.push_back(make_float4((float)cx, (float)cy, (float)cz, nr2_scan(r)));
             mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
             mov_id.push_back((int32_t)i);
         } else {
@@ -828,18 +864,14 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
             const float w = (float)(fx * fx + fy * fy + fz * fz - r * r);
             if (is_planar[i]) {
                 plan.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
-                plan_nr2.push_back((float)-(r * r));
+                plan_nr2.push_back(nr2_scan(r));
                 plan_id.push_back((int32_t)i);
             } else {
                 stat.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
-                stat_nr2.push_back((float)-(r * r));
+                stat_nr2.push_back(nr2_scan(r));
                 stat_id.push_back((int32_t)i);
             }
             cmax = std::max(cmax, std::sqrt(fx * fx + fy * fy + fz * fz));
-        }
-        if (!is_big[i]) {  // how far from the frame's origin a scan sphere reaches, over its whole motion
-            const double ex = cx + s->dcx[i], ey = cy + s->dcy[i], ez = cz + s->dcz[i];
-            reach = std::max(reach, std::max(std::sqrt(cx * cx + cy * cy + cz * cz), std::sqrt(ex * ex + ey * ey + ez * ez)) + r);
         }
     }
     // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
@@ -994,12 +1026,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
-    {
-        std::vector<int32_t> id_slot(s->n_spheres, -1);
-        for (size_t k = 0; k < scan_id.size(); ++k)
-            if (scan_id[k] >= 0) id_slot[(size_t)scan_id[k]] = (int32_t)k;
-        UP(dev_copy(c, id_slot.data(), id_slot.size(), &D.id_slot));
-    }
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
     std::vector<BigSphere> big(big_id.size());
     for (size_t k = 0; k < big_id.size(); ++k) {
@@ -1061,7 +1087,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         return m;
     };
     D.lists.np_pad = (int32_t)plan.size();
-    c->has_planar = !plan.empty();
+    c->scan_mode = (stat.empty() && plan.empty() && mov_a.empty()) ? 2 : !plan.empty() ? 1 : 0;
     D.lists.plan_axis = plan_axis;
     D.lists.plan_val = plan_val;
     D.lists.plan_levels = plan_levels;
@@ -1087,7 +1113,7 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     for (uint32_t bufs = 1; bufs <= 2; ++bufs) {
         const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(bufs);
         if (lds_bytes > 65536) continue;
-        RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2, c->has_planar), kBlock, lds_bytes));
+        RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2, c->scan_mode), kBlock, lds_bytes));
     }
     c->acc_bufs = (occ[2] >= occ[1] && occ[2] > 0) ? 2 : 1;
     if (c->dbg_tile_bufs && occ[c->dbg_tile_bufs] > 0) c->acc_bufs = (uint32_t)c->dbg_tile_bufs;  // rt_debug_set_tile_buffers
@@ -1174,7 +1200,7 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
         A.unit_counter = reinterpret_cast<unsigned int*>(counters + 1);
         RT_HIP(c, hipMemsetAsync(counters + 1, 0, sizeof(unsigned long long), c->stream));
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
-        hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2, c->has_planar), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
+        hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2, c->scan_mode), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
         done += spp_l;
         ++launches;
@@ -1277,6 +1303,11 @@ int rt_debug_scan_layout(rt_ctx* c, int32_t out[8]) {
     const int32_t v[8] = {c->S.n_big, L.ns_pad, L.np_pad, L.nm_pad, L.np_pad > 0 ? L.plan_axis : -1,
                           L.nm_pad > 0 ? L.mov_axes : 0, (int32_t)c->acc_bufs, c->has_noise ? 1 : 0};
     for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return RT_OK;
+}
+int rt_debug_set_direct(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_BAD_ARG;
+    c->dbg_no_direct = on == 0;
     return RT_OK;
 }
 int rt_debug_set_tile_buffers(rt_ctx* c, int n) {

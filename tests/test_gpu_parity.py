@@ -12,16 +12,18 @@ import numpy as np
 import pytest
 
 from conftest import golden, rmse_gamma
-from helpers import check_hits, rel_err, scene_checksum
+from helpers import check_hits, check_image, rel_err, scene_checksum
 
 pytestmark = pytest.mark.gpu
 
-# Rays whose TIE margin (oracle_capi.cpp::decision_margin without its discriminant term: "5 % of t_min for a root
-# on the range boundary / 1e-3 relative near-tie between two spheres") is below 1 are excluded from the bit-exact
-# checks: the device ORDERS candidates by fp32 keys.  Hit/miss itself has no exempt band since round 2: the fp32 scan
-# is conservative and the nominee is decided in f64, with a retrace when it is rejected (rt_device.h, kRetry), so a
-# grazing ray must agree with the oracle bit for bit.  Excluded counts are printed per case (~0.01 % of generic rays;
-# round 1's bar, which exempted 16 fp32 ulps around a grazing discriminant, excluded 0.1-5 %).
+# Rays whose TIE margin (oracle_capi.cpp::decision_margin without its discriminant term: a root within 1e-6 relative
+# of t_min / two spheres within 1e-9 relative in depth) is below 1 are excluded from the bit-exact checks: those bands
+# stand for last-bit differences between two f64 evaluations of the same formula, not for fp32.  Since round 3 every
+# decision is made in f64 on the device: the fp32 scan only proposes candidates (conservatively, with keys that are
+# lower bounds of the depth), the nominee is decided in f64, and the trace goes on while any undecided candidate's key
+# lies below the exact best (rt_device.h, kRetry); exact ties go to the first sphere in world order as in
+# hit.rs:100-110.  Excluded counts are printed per case (0 in nearly every batch; rounds 1-2 exempted 16 fp32 ulps
+# around a grazing discriminant, then 5 % of t_min and 1e-3 in depth: 0.01-14 % of a batch).
 EPS_MARGIN = 1.0
 TOL = 1e-5         # north_star: t, normal, scatter direction within 1e-5 relative
 
@@ -56,7 +58,7 @@ def test_intersect_batches(ctx, api, name, case):
     ctx.upload(w.scene)
     got = ctx.intersect_batch(g[f"{case}_rays"], 1e-3)
     # the grazing set aims within r*(1 +- 4e-3..3e-2) of a limb on purpose: part of it lands inside the band
-    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL, max_excluded=0.005)
+    stats = check_hits(got, g[f"{case}_hits"], EPS_MARGIN, TOL)
     print(name, case, stats)
     miss = got["hit"] == 0
     assert not got["t"][miss].any() and not got["normal"][miss].any()  # a miss is all zeros
@@ -80,9 +82,56 @@ def test_intersect_large_incoherent_batch(ctx, api, orc, name):
     rays = np.concatenate([cam, rnd])
     got = ctx.intersect_batch(rays)
     exp = orc.intersect_batch(w.scene, rays)
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.001)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.0001)
     print(name, st, "hits", int(exp["hit"].sum()))
     assert exp["hit"].sum() > 0.5 * len(rays)
+
+
+@pytest.mark.parametrize("name", ["FinalStatic", "Random", "Balls", "TwoSpheres", "PerlinNoise2"])
+def test_scattered_ray_generations(ctx, api, orc, name):
+    """The rays a render traces: camera rays, then four generations of rays scattered off the hits (rt_scatter_batch with
+    random uniforms), i.e. origins ON surfaces and Lambertian directions n + S of any length, down to |d| ~ 1e-3, where
+    t_min = 1e-3 is a distance of 1e-6 and the reference (f64) finds the exit of the sphere a rounded hit point sits
+    just inside of.  Every generation against the live oracle, bit-exact; scenes of a handful of spheres both in the
+    direct (all-f64) layout the render kernel uses for them and with scan lists (rt_debug_set_direct)."""
+    w = api.World(name, seed=1, aspect=1.5)
+    rng = np.random.default_rng(3)
+    n = 1 << 17
+    ctx.upload(w.scene)
+    direct_scene = ctx.debug_scan_layout()["scan"] == 2
+    rays = ctx.camera_rays(w.camera, rng.random((n, 2), dtype=np.float32), rng.random((n, 4), dtype=np.float32))
+    tiny = 0
+    try:
+        for gen in range(5):
+            exp = orc.intersect_batch(w.scene, rays)
+            got = None
+            for direct in ((True, False) if direct_scene else (True,)):
+                ctx.debug_set_direct(direct)
+                ctx.upload(w.scene)
+                assert (ctx.debug_scan_layout()["scan"] == 2) == (direct and direct_scene)
+                g = ctx.intersect_batch(rays)
+                st = check_hits(g, exp, EPS_MARGIN, TOL, max_excluded=0.0001)
+                got = g if got is None else got
+                print(name, "generation", gen, "direct" if direct and direct_scene else "scan", st, "hits", int(exp["hit"].sum()))
+            tiny += int((np.linalg.norm(rays["dir"], axis=1) < 0.02).sum())
+            m = got["hit"] == 1
+            if not m.any():
+                break
+            u = rng.random((int(m.sum()), 4), dtype=np.float32)
+            # half of the uniforms aimed so that the unit-sphere sample nearly cancels the normal (map_unit_sphere:
+            # z = 1 - 2 u0, angle = u1 turns): Lambertian directions n + S of length 1e-3 .. 1e-1
+            nrm = got["normal"][m].astype(np.float64)
+            tgt = -nrm + rng.normal(size=nrm.shape) * 10.0 ** rng.uniform(-3.5, -1.0, (len(nrm), 1))
+            tgt /= np.linalg.norm(tgt, axis=1, keepdims=True)
+            aim = rng.random(len(nrm)) < 0.5
+            u[aim, 0] = np.clip((1.0 - tgt[aim, 2]) / 2.0, 0.0, np.nextafter(np.float32(1), np.float32(0)))
+            u[aim, 1] = np.mod(np.arctan2(tgt[aim, 1], tgt[aim, 0]) / (2 * np.pi), 1.0).astype(np.float32) % np.float32(1)
+            sc = ctx.scatter_batch(rays[m], got[m], u)
+            rays = np.zeros(int(m.sum()), api.ray_dtype)
+            rays["origin"], rays["dir"], rays["time"] = sc["origin"], sc["dir"], sc["time"]
+    finally:
+        ctx.debug_set_direct(True)
+    print(name, "rays with |d| < 0.02:", tiny)
 
 
 def test_moving_spheres_at_any_ray_time(ctx, api, orc):
@@ -100,7 +149,7 @@ def test_moving_spheres_at_any_ray_time(ctx, api, orc):
     rays["time"][: n // 4] = rng.random(n // 4)         # ... and the first waves hold none
     got = ctx.intersect_batch(rays)
     exp = orc.intersect_batch(w.scene, rays)
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.005)  # at time 3 the spheres have risen into one another: more near-ties
+    st = check_hits(got, exp, EPS_MARGIN, TOL)
     moving = np.abs(w.arrays()["dc"]).sum(1) > 0
     hit_moving = exp["hit"].astype(bool) & moving[np.clip(exp["sphere_id"], 0, None)]
     print(st, "hits on moving spheres", int(hit_moving.sum()), "of them at time outside [0,1]",
@@ -232,7 +281,7 @@ def test_six_noise_textures_in_one_scene(ctx, api, orc):
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
     r = rmse_gamma(img, ref)
     print("render rmse(gamma)", r, "rays", int(st.rays_traced), rays_ref)
-    assert r < 0.01 and abs(int(st.rays_traced) - rays_ref) < 0.005 * rays_ref
+    assert r < 5e-5 and int(st.rays_traced) == rays_ref  # measured 1.1e-5, ray counts equal
     # one more pair than fits
     t7 = api.Texture.from_buffer_copy(texs[0])
     t7.table_id = 3
@@ -295,7 +344,7 @@ def test_noise_textures_on_a_planar_grid(ctx, api, orc):
     img, st = res[(True, 0)]
     r = rmse_gamma(img, ref)
     print("render rmse(gamma)", r, "rays", int(st.rays_traced), rays_ref)
-    assert r < 0.02 and abs(int(st.rays_traced) - rays_ref) < 0.01 * rays_ref
+    assert r < 3e-4 and abs(int(st.rays_traced) - rays_ref) <= 1e-3 * rays_ref  # measured 7.8e-5, ray counts equal
     for key in ((True, 1), (False, 0)):
         assert np.array_equal(res[key][0], img) and res[key][1].rays_traced == st.rays_traced, key
 
@@ -314,12 +363,16 @@ def test_render_path_level_parity_small(ctx, api):
     assert st.samples == 100 * 56 * 16
     assert abs(int(st.rays_traced) - int(g["FinalStatic16_rays"])) < 0.005 * int(g["FinalStatic16_rays"])
     r = rmse_gamma(img, ref)
-    assert r < 0.01, r  # MC noise at 16 spp would be ~0.1: this is path-level agreement
+    print("path-level rmse(gamma)", r, "median abs", float(np.median(np.abs(img - ref))))
+    assert r < 4e-4, r  # measured 9.3e-5; MC noise at 16 spp would be ~0.1: this is path-level agreement
     assert np.median(np.abs(img - ref)) < 1e-5
 
 
-@pytest.mark.parametrize("name,tol", [("FinalStatic", 0.004), ("Random", 0.004), ("PerlinMarbled", 0.004),
-                                      ("PerlinTurbulence", 0.006), ("TwoSpheres", 0.006)])
+# tolerances: 3-4x what is measured (1.7e-5, 3.9e-5, 1.2e-5, 1.6e-5, 7.0e-5: the device follows the oracle's paths sample for
+# sample, what is left is fp32 shading).  Round 1's lost-hit bug (a rejected nominee fell back to the sky) measured
+# 8e-5 .. 1e-4 on FinalStatic and Random and fails these; the visible threshold is 1/255 = 3.9e-3.
+@pytest.mark.parametrize("name,tol", [("FinalStatic", 6e-5), ("Random", 1.5e-4), ("PerlinMarbled", 5e-5),
+                                      ("PerlinTurbulence", 6e-5), ("TwoSpheres", 2.5e-4)])
 def test_render_converged_rmse_after_gamma(ctx, api, name, tol):
     """north_star check (2): the converged image matches the reference CPU render (oracle, f64, BVH) within an
     RMSE tolerance after gamma. Tolerances are ~10x below the visible threshold (1/255 = 0.0039 per level)."""
@@ -336,7 +389,7 @@ def test_render_converged_rmse_after_gamma(ctx, api, name, tol):
     rays_rel = abs(int(st.rays_traced) - int(g[f"{name}_rays"])) / int(g[f"{name}_rays"])
     print(name, "rmse(gamma)", r, "rays rel diff", rays_rel, "kernel_ms", st.kernel_ms)
     assert r < tol, (name, r)
-    assert rays_rel < 0.003
+    assert rays_rel < 0.0015  # measured 9e-5 .. 4.5e-4
     enc, bad = ctx.encode(img)  # Screen::encode (screen.rs:26-45) on the device
     assert bad == 0
     exp_enc = ((255.99 * np.sqrt(img.astype(np.float64))).astype(np.uint32) * [65536, 256, 1]).sum(-1).reshape(-1)
@@ -466,6 +519,7 @@ def test_tiny_and_ragged_images(ctx, api, orc, W, H, spp):
     assert img.shape == (H, W, 3) and st.samples == W * H * spp
     assert np.isfinite(img).all() and img.min() >= 0 and img.max() <= 1
     # a handful of paths: every one follows the oracle's unless a ray lands within rounding of a decision
+    print(W, H, spp, 'rmse(gamma)', rmse_gamma(img, ref), 'rays', int(st.rays_traced), rays_ref)
     assert np.median(np.abs(img - ref)) < 1e-5 and rmse_gamma(img, ref) < 0.05
     assert abs(int(st.rays_traced) - rays_ref) <= max(2, 0.02 * rays_ref)
 
@@ -532,7 +586,7 @@ def test_motion_along_other_axes(ctx, api, orc, axes):
     p = api.make_params(96, 64, 16, max_depth=10, seed=4)
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
-    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+    check_image("motion axes render vs oracle", img, ref, 3e-3, s1.rays_traced, rays_ref, 2e-3)  # measured 7.1e-4 .. 8.8e-4, rays 2e-4 .. 3e-4
 
 
 @pytest.mark.parametrize("axis", [0, 1, 2])
@@ -594,7 +648,7 @@ def test_planar_scan_list(ctx, api, orc, axis):
     p = api.make_params(96, 64, 16, max_depth=12, seed=4)
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
-    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+    check_image("planar list render vs oracle", img, ref, 3e-3, s1.rays_traced, rays_ref, 1e-3)  # measured 8.0e-4 .. 9.3e-4, rays <= 1.5e-4
     ctx.debug_set_planar_list(False)
     try:
         ctx.upload(fs.scene)
@@ -684,7 +738,7 @@ def test_caller_built_scenes_up_to_the_limit(ctx, api, orc, n, moving_every):
     p = api.make_params(96, 64, 8, max_depth=12, seed=11)
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
-    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+    check_image(f"caller-built n={n} render vs oracle", img, ref, {16384: 2.5e-2, 2048: 1.2e-2, 1: 1e-6, 9: 1e-6}[n], s1.rays_traced, rays_ref, 2e-3)  # measured 8.9e-3 / 3.8e-3 / 9e-9 / 1.4e-8 (8 spp), rays <= 6.1e-4
 
 
 def test_several_big_spheres_one_of_them_moving(ctx, api, orc):
@@ -721,7 +775,7 @@ def test_several_big_spheres_one_of_them_moving(ctx, api, orc):
     p = api.make_params(96, 64, 16, max_depth=12, seed=3)
     img, s1 = ctx.render(cam, p)
     ref, _, rays_ref = orc.render(fs.scene, cam, p, mode=orc.MODE_COUNTER, n_threads=4)
-    assert rmse_gamma(img, ref) < 0.02 and abs(int(s1.rays_traced) - rays_ref) < 0.02 * rays_ref
+    check_image("big spheres render vs oracle", img, ref, 1.5e-3, s1.rays_traced, rays_ref, 5e-4)  # measured 4.6e-4, rays 5.7e-5
 
 
 def _scaled_world(api, name, k, aspect):
@@ -767,7 +821,7 @@ def test_scaled_scenes(ctx, api, orc, name, k):
     rays = np.concatenate([rays, rnd])
     got = ctx.intersect_batch(rays, 1e-3 * k)
     exp = orc.intersect_batch(fs.scene, rays, 1e-3 * k)
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.001)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.0001)
     print(name, k, st, "hits", int(exp["hit"].sum()))
     assert exp["hit"].sum() > 0.5 * len(rays)
     # same counter streams, same geometry up to scale: the image is the unscaled scene's image
@@ -777,7 +831,7 @@ def test_scaled_scenes(ctx, api, orc, name, k):
     ref, st0 = ctx.render(w.camera, api.make_params(240, 160, 64, seed=w.render_seed))
     r = rmse_gamma(img, ref)
     print(name, k, "rmse(gamma) scaled vs unscaled", r, "rays", st1.rays_traced, st0.rays_traced)
-    assert r < 0.01 and abs(int(st1.rays_traced) - int(st0.rays_traced)) < 3e-3 * st0.rays_traced
+    assert r < 8e-4 and abs(int(st1.rays_traced) - int(st0.rays_traced)) < 5e-4 * st0.rays_traced  # measured 9e-5 .. 2.4e-4 (64 spp), rays <= 1.2e-4
 
 
 def test_small_spheres_far_from_the_rays(ctx, api, orc):
@@ -807,9 +861,9 @@ def test_small_spheres_far_from_the_rays(ctx, api, orc):
     rays["dir"] = (tgt + perp * off[:, None] - o) * rng.uniform(0.5, 2.0, (n, 1)) / dist[:, None]
     got = ctx.intersect_batch(rays)
     exp = orc.intersect_batch(fs.scene, rays)
-    # near-ties are RELATIVE to the distance (1e-3 of ~450 = 0.45 units here, the size of the gaps between 400 spheres
-    # in a 6-unit box): ~3 % of these rays see two spheres that close in depth; hit/miss has no exempt band
-    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.05)
+    # (rounds 1-2 exempted near-ties of 1e-3 relative in depth -- 0.45 units at this distance, the size of the gaps
+    # between the spheres, ~3 % of these rays; the f64 tie chain leaves nothing to exempt)
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.0001)
     print(st, "hits", int(exp["hit"].sum()), "excluded by round 1's discriminant band:", int((exp["margin"] < 1).sum()))
     assert 0.3 * n < exp["hit"].sum() < 0.95 * n
 
@@ -824,7 +878,7 @@ def test_max_depth_semantics(ctx, api, orc):
         p = api.make_params(64, 36, 64, max_depth=depth, seed=5)
         img, st = ctx.render(w.camera, p)
         ref, _, rays = orc.render(w.scene, w.camera, p, n_threads=8)
-        assert rmse_gamma(img, ref) < 0.01, depth
+        check_image(f"depth {depth}", img, ref, 1e-6 if depth == 1 else 5e-4)  # measured 2.4e-9 / 1.4e-4 .. 1.6e-4
         assert abs(int(st.rays_traced) - rays) <= 0.003 * rays
         if prev is not None:
             assert img.mean() >= prev - 1e-3  # more bounces never darken

@@ -49,12 +49,12 @@ for case in range(n_cases):
     exp = orc.intersect_batch(fs.scene, rays, t_min)
     try:
         try:
-            st = check_hits(got, exp, 1.0, 1e-5, max_excluded=0.1)  # rays that start inside / on big spheres: many t_min-boundary cases
+            st = check_hits(got, exp, 1.0, 1e-5, max_excluded=0.001)
         except AssertionError as e:
             if "too many rays excluded" not in str(e):
                 raise
             st = check_hits(got, exp, 1.0, 1e-5, max_excluded=0.5)  # not a mismatch: check the rest of the batch anyway
-            st = dict(st, note="more than 10 % of the rays within the margin of a decision")
+            st = dict(st, note="more than 0.1 % of the rays within the margin of a decision")
     except AssertionError as e:
         print("CASE", seed0 + case, "n", n, "ext", ext, "motion axes", mode, "big", n_big, "plane axis", planar, "FAILED:", str(e)[:300], flush=True)
         continue

@@ -1,6 +1,6 @@
 """Debug: trigger statistics of the lazy-root scan (needs librtx_stats.so built with -DRT_STATS)."""
 import ctypes as C, os, sys
-os.environ["RTX_HIP_LIB"] = os.path.join(os.path.dirname(__file__), "..", "raytracing_amd", "librtx_stats.so")
+os.environ["RTX_HIP_LIB"] = os.path.join(os.path.dirname(__file__), "..", "raytracing_amd", os.environ.get("STATS_LIB", "librtx_stats.so"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 from raytracing_amd import api
 api.allow_lib_override()  # A/B tooling: RTX_HIP_LIB names the build under test
