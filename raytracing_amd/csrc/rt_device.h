@@ -822,7 +822,11 @@ __device__ __forceinline__ HitRec hit_end(const SceneT& S, const Ray& r, const H
             w.t_best = t; w.id_best = id;
         }
         // every candidate not decided yet has a key >= second: final unless that may still be closer than the best
+#ifdef RT_X_NORETRY  // tolerance-sensitivity experiment (tools/tolerance_sensitivity.py): round 1's behaviour, a rejected nominee is final
+        if (false) {
+#else
         if (second < hit_key(w, C)) {
+#endif
             h.sphere = kRetry; h.front = slot; h.t = __uint_as_float(best);
             h.p = {__int_as_float(w.id_best), __int_as_float(__double2loint(w.t_best)), __int_as_float(__double2hiint(w.t_best))};
             h.n = {0, 0, 0};

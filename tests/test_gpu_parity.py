@@ -183,6 +183,33 @@ def test_intersect_edge_cases(ctx, api, orc):
     c2.close()
 
 
+def _scatter_decision_margin(api, scene, rays, hits, u):
+    """Distance of each scatter call from the nearest branch decision of its material, in f64 from the inputs
+    (material.rs:91-111: TIR `eta sin > 1`, Schlick coin `u0 < schlick`; material.rs:66-70: Metal's `refl . n <= 0`).
+    Lambertian has no branch (inf)."""
+    d = rays["dir"].astype(np.float64)
+    ud = d / np.linalg.norm(d, axis=1, keepdims=True)
+    n = hits["normal"].astype(np.float64)
+    out = np.full(len(rays), np.inf)
+    for i in range(len(rays)):
+        mat = scene.materials[int(hits["material_id"][i])]
+        dn = float(ud[i] @ n[i])
+        if mat.type == api.RT_MAT_DIELECTRIC:
+            eta = 1.0 / mat.ior if hits["front_face"][i] else mat.ior
+            c = min(-dn, 1.0)
+            sn = np.sqrt(max(0.0, 1.0 - c * c))
+            r0 = ((1 - eta) / (1 + eta)) ** 2
+            out[i] = min(abs(eta * sn - 1.0), abs(float(u[i, 0]) - (r0 + (1 - r0) * (1 - c) ** 5)))
+        elif mat.type == api.RT_MAT_METAL:
+            z = 1.0 - 2.0 * float(u[i, 0])
+            rr = np.sqrt(max(0.0, 1.0 - z * z))
+            a = 2 * np.pi * float(u[i, 1])
+            sph = np.array([rr * np.cos(a), rr * np.sin(a), z])
+            refl = ud[i] - 2 * dn * n[i] + mat.fuzz * sph
+            out[i] = abs(float(refl @ n[i]))
+    return out
+
+
 @pytest.mark.parametrize("name", ["FinalStatic", "Random", "Balls"])
 def test_scatter_batches(ctx, api, name):
     g = golden(f"rays_{name}.npz")
@@ -203,10 +230,18 @@ def test_scatter_batches(ctx, api, name):
         # a Lambertian n + S that nearly cancels has an ill-conditioned direction: relative to |n| = 1 instead
         abs_err = np.linalg.norm(got["dir"][m].astype(np.float64) - exp["dir"][m], axis=1)
         bad &= abs_err > TOL
-        assert bad.sum() <= max(2, 2e-3 * m.sum()), (name, pre, int(bad.sum()), float(err.max()))
-        assert np.abs(got["albedo"][m] - exp["albedo"][m]).max() < 1e-6 or name == "Random"
-        if name == "Random":  # checker ground: sin(10 x) sign can flip within rounding of a zero crossing
-            assert (np.abs(got["albedo"][m] - exp["albedo"][m]).max(1) > 1e-6).sum() <= 3
+        # an outlier is legitimate only ON a decision boundary (where fp32 and f64 may take different branches): each one
+        # must be within 1e-5 of the Schlick coin / TIR threshold (Dielectric) or of refl.n = 0 (Metal's below-surface
+        # correction).  Measured on these fixtures: no outlier at all.
+        if bad.any():
+            margin = _scatter_decision_margin(api, s, rays[m][bad], hits[m][bad], u[m][bad])
+            assert (margin < 1e-5).all(), (name, pre, int(bad.sum()), margin)
+        d_alb = np.abs(got["albedo"][m] - exp["albedo"][m]).max(1)
+        if name == "Random":  # checker ground: a differing albedo must sit on a zero crossing of sin(10 x) along some axis
+            p = hits["point"][m][d_alb > 1e-6].astype(np.float64)
+            assert len(p) <= 3 and (np.abs(np.sin(10.0 * p)).min(1) < 1e-4).all(), p
+        else:
+            assert d_alb.max() < 1e-6
         assert rel_err(got["origin"][m], exp["origin"][m]).max() < TOL
         assert np.array_equal(got["time"][m], exp["time"][m].astype(np.float32))
         kinds = set(mats[hits["material_id"][m]].tolist())
@@ -430,6 +465,7 @@ def test_render_properties_full_size(ctx, api):
 
 
 @pytest.mark.parametrize("name,W,H,spp,off", [
+    ("FinalStatic", 1200, 800, 1000, 0),       # BASELINE configs[1]: the headline workload at its own size
     ("Random", 1200, 800, 500, 0),             # BASELINE configs[2]: motion blur, 484 moving spheres
     ("PerlinNoise2", 1200, 800, 500, 0),       # BASELINE configs[3]: noise / turbulence / marble
     ("PerlinTurbulence", 1200, 800, 500, 0),
