@@ -255,16 +255,19 @@ int rt_rng_batch(rt_ctx* ctx, uint64_t seed, const uint32_t* counters4, uint32_t
  * device g renders sample indices [first_g, first_g + count_g) of every pixel (rt_partition_spp), so the counter-RNG
  * streams are disjoint and the N-device image equals the 1-device image up to fp32 summation order.  The scene is
  * replicated; the only exchange step is ONE ncclReduce(sum, float, width*height*3) onto the first device over
- * xGMI.  RCCL is loaded at run time by rt_multi_create (RT_ERR_RCCL if it is missing). */
+ * xGMI.  RCCL is loaded at run time by rt_multi_create; if it is missing or a communicator cannot be formed, the
+ * parts are copied to the first device (hipMemcpyPeerAsync) and added there instead: same sums, n - 1 copies
+ * (rt_multi_stats.exchange tells which). */
 typedef struct rt_multi rt_multi;
 
 typedef struct rt_multi_stats {
     uint64_t rays_traced; /* all devices */
     uint64_t samples;     /* width*height*spp */
     float kernel_ms;      /* slowest device's path-trace kernel time */
-    float reduce_ms;      /* the RCCL reduce, events on the root device's stream */
+    float reduce_ms;      /* the exchange step, events on the root device's stream */
     uint32_t n_devices;
-    uint32_t reserved;
+    uint32_t exchange;    /* how the sums were combined: 0 = one ncclReduce, 1 = copied to the root device and added
+                             there (no communicator could be formed: librccl missing or ncclCommInitAll failed) */
     float device_kernel_ms[RT_MAX_DEVICES];
 } rt_multi_stats;
 

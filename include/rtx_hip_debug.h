@@ -42,6 +42,14 @@ int rt_debug_set_tile_buffers(rt_ctx* ctx, int n);
  *        tile buffers per wave, noise variant (0/1)}. */
 int rt_debug_scan_layout(rt_ctx* ctx, int32_t out[8]);
 
+/* Process-wide switches read by rt_multi_create, so that EVERY line of the multi-device path can run on a box with one
+ * GPU.  flags: bit 0 = a device ordinal may be listed more than once (each entry gets its own rt_ctx, stream and
+ * workspace on that GPU); bit 1 = never use RCCL.  Either way the exchange step then copies each part's sums to the
+ * root device (hipMemcpyPeerAsync) and adds them there instead of one ncclReduce -- the fallback rt_multi_create also
+ * takes by itself when librccl is missing or ncclCommInitAll fails.  0 restores the default.  No scaling number may be
+ * quoted from such a run. */
+int rt_debug_multi(int flags);
+
 #ifdef __cplusplus
 }
 #endif

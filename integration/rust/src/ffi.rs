@@ -134,9 +134,9 @@ pub struct rt_multi_stats {
     pub rays_traced: u64,
     pub samples: u64,
     pub kernel_ms: f32, // slowest device
-    pub reduce_ms: f32, // the one ncclReduce over xGMI
+    pub reduce_ms: f32, // the exchange step (one ncclReduce over xGMI, or the copy-and-add fallback)
     pub n_devices: u32,
-    pub reserved: u32,
+    pub exchange: u32, // 0 = ncclReduce, 1 = parts copied to the first device and added there
     pub device_kernel_ms: [f32; RT_MAX_DEVICES],
 }
 

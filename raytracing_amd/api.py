@@ -96,7 +96,7 @@ class Stats(C.Structure):
 class MultiStats(C.Structure):
     _fields_ = [
         ("rays_traced", C.c_uint64), ("samples", C.c_uint64), ("kernel_ms", C.c_float), ("reduce_ms", C.c_float),
-        ("n_devices", C.c_uint32), ("reserved", C.c_uint32), ("device_kernel_ms", C.c_float * RT_MAX_DEVICES),
+        ("n_devices", C.c_uint32), ("exchange", C.c_uint32), ("device_kernel_ms", C.c_float * RT_MAX_DEVICES),
     ]
 
 
@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
     "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers", "rt_debug_set_planar_list",
-    "rt_debug_scan_layout", "rt_debug_set_direct",
+    "rt_debug_scan_layout", "rt_debug_set_direct", "rt_debug_multi",
 ]
 
 _lib = None
@@ -187,6 +187,8 @@ def load() -> C.CDLL:
     lib.rt_debug_set_work_units.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_int32]
     lib.rt_debug_set_scan_order.argtypes = [vp, C.c_int]
     lib.rt_debug_set_tile_buffers.argtypes = [vp, C.c_int]
+    if hasattr(lib, "rt_debug_multi"):
+        lib.rt_debug_multi.argtypes = [C.c_int]
     if hasattr(lib, "rt_debug_set_direct"):
         lib.rt_debug_set_direct.argtypes = [vp, C.c_int]
     if hasattr(lib, "rt_debug_set_planar_list"):  # (absent from older builds that tools/ab*.sh compare against)
@@ -358,6 +360,14 @@ def partition_spp(total_spp: int, n_parts: int, part: int):
     if rc != RT_OK:
         raise RtError(rc, "bad partition arguments")
     return int(first.value), int(count.value)
+
+
+def debug_multi(flags: int = 0) -> None:
+    """include/rtx_hip_debug.h rt_debug_multi: bit 0 = a device may be listed several times, bit 1 = no RCCL (the
+    copy-and-add exchange step); process-wide, read by the next MultiContext."""
+    rc = load().rt_debug_multi(int(flags))
+    if rc != RT_OK:
+        raise RtError(rc, "bad rt_debug_multi flags")
 
 
 class MultiContext:

@@ -399,6 +399,12 @@ __global__ void finalize_kernel(const unsigned long long* __restrict__ accum, fl
     if (i < n) out[i] = (float)((double)accum[i] * scale);
 }
 
+// the copy-and-add form of the multi-device exchange step (rt_multi_render without RCCL): acc += part
+__global__ void add_kernel(float* __restrict__ acc, const float* __restrict__ part, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) acc[i] += part[i];
+}
+
 __global__ void scale_kernel(const float* __restrict__ in, float* __restrict__ out, size_t n, float scale) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = in[i] * scale;
@@ -1484,11 +1490,18 @@ thread_local std::string g_multi_create_error;
 
 struct rt_multi {
     std::vector<rt_ctx*> ctx;      // one per device, in the caller's order; ctx[0] is the reduce root
-    std::vector<ncclComm_t> comm;
+    std::vector<ncclComm_t> comm;  // empty when the exchange step runs without RCCL (use_rccl == false)
     std::vector<float*> dsum;      // per device: W*H*3 radiance sums of its share
+    float* stage = nullptr;        // copy-and-add exchange: a part's sums on the root device, W*H*3 floats
     size_t dsum_cap = 0;
+    bool use_rccl = true;
     std::string err;
 };
+namespace {
+// rt_debug_multi (include/rtx_hip_debug.h): bit 0 = a device ordinal may be listed more than once, bit 1 = never use
+// RCCL.  Process-wide, read by rt_multi_create.
+int g_multi_debug = 0;
+}  // namespace
 
 extern "C" {
 
@@ -1508,8 +1521,9 @@ void rt_multi_destroy(rt_multi* m) {
         if (m->ctx[i]) (void)hipSetDevice(m->ctx[i]->device);
         if (i < m->comm.size() && m->comm[i] && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(m->comm[i]);
         if (i < m->dsum.size() && m->dsum[i]) (void)hipFree(m->dsum[i]);
-        rt_destroy(m->ctx[i]);
     }
+    if (m->stage && !m->ctx.empty() && m->ctx[0]) { (void)hipSetDevice(m->ctx[0]->device); (void)hipFree(m->stage); }
+    for (rt_ctx* c : m->ctx) rt_destroy(c);
     delete m;
 }
 
@@ -1518,14 +1532,12 @@ int rt_multi_create(const int* device_ordinals, int n_devices, rt_multi** out) {
     if (!out) return bad(RT_ERR_BAD_ARG, "out is NULL");
     *out = nullptr;
     if (!device_ordinals || n_devices < 1 || n_devices > RT_MAX_DEVICES) return bad(RT_ERR_BAD_ARG, "need 1..RT_MAX_DEVICES device ordinals");
+    bool repeated = false;
     for (int i = 0; i < n_devices; ++i)
-        for (int j = 0; j < i; ++j)
-            if (device_ordinals[i] == device_ordinals[j]) return bad(RT_ERR_BAD_ARG, "a device ordinal is listed twice");
-    std::string err;
-    if (!g_rccl.load(err)) return bad(RT_ERR_RCCL, err);
+        for (int j = 0; j < i; ++j) repeated |= device_ordinals[i] == device_ordinals[j];
+    if (repeated && !(g_multi_debug & 1)) return bad(RT_ERR_BAD_ARG, "a device ordinal is listed twice");
     rt_multi* m = new rt_multi();
     m->ctx.assign(n_devices, nullptr);
-    m->comm.assign(n_devices, nullptr);
     m->dsum.assign(n_devices, nullptr);
     for (int i = 0; i < n_devices; ++i) {
         const int rc = rt_create(device_ordinals[i], &m->ctx[i]);
@@ -1535,11 +1547,19 @@ int rt_multi_create(const int* device_ordinals, int n_devices, rt_multi** out) {
             return rc;
         }
     }
-    const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, device_ordinals);  // rank i = device_ordinals[i]
-    if (r != ncclSuccess) {
-        g_multi_create_error = std::string("ncclCommInitAll: ") + g_rccl.GetErrorString(r);
-        rt_multi_destroy(m);
-        return RT_ERR_RCCL;
+    // The exchange step is one ncclReduce over xGMI.  Where a communicator cannot be formed -- librccl
+    // missing, ncclCommInitAll failing, or (debug hook) one device listed several times, which RCCL refuses -- the
+    // parts are copied to the root device and added there (hipMemcpyPeerAsync + add_kernel): same sums, n - 1 copies.
+    m->use_rccl = !repeated && !(g_multi_debug & 2);
+    if (m->use_rccl) {
+        std::string err;
+        if (!g_rccl.load(err)) {
+            m->use_rccl = false;
+        } else {
+            m->comm.assign(n_devices, nullptr);
+            const ncclResult_t r = g_rccl.CommInitAll(m->comm.data(), n_devices, device_ordinals);  // rank i = device_ordinals[i]
+            if (r != ncclSuccess) { m->comm.clear(); m->use_rccl = false; }
+        }
     }
     *out = m;
     return RT_OK;
@@ -1557,21 +1577,40 @@ int rt_multi_upload_scene(rt_multi* m, const rt_scene* scene) {
 int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float* out_rgb, rt_multi_stats* stats) {
     if (!m) return RT_ERR_BAD_ARG;
     const int n = (int)m->ctx.size();
-    auto fail_from = [&](rt_ctx* c, int rc) { m->err = c->err; return rc; };
+    // An error return must not leave work in flight on the devices already launched: wait for every stream first.
+    auto drain = [&]() {
+        for (int i = 0; i < n; ++i) {
+            (void)hipSetDevice(m->ctx[i]->device);
+            (void)hipStreamSynchronize(m->ctx[i]->stream);
+        }
+    };
+    auto fail_from = [&](rt_ctx* c, int rc) { m->err = c->err; drain(); return rc; };
+    auto fail_msg = [&](int rc, const std::string& msg) { m->err = msg; drain(); return rc; };
     int rc = check_render_args(m->ctx[0], cam, p, out_rgb);
-    if (rc != RT_OK) return fail_from(m->ctx[0], rc);
+    if (rc != RT_OK) { m->err = m->ctx[0]->err; return rc; }
     const size_t n_el = (size_t)p->width * p->height * 3;
+    rt_ctx* root = m->ctx[0];
     if (m->dsum_cap < n_el) {
         for (int i = 0; i < n; ++i) {
             (void)hipSetDevice(m->ctx[i]->device);
             if (m->dsum[i]) (void)hipFree(m->dsum[i]);
             m->dsum[i] = nullptr;
         }
+        (void)hipSetDevice(root->device);
+        if (m->stage) (void)hipFree(m->stage);
+        m->stage = nullptr;
         m->dsum_cap = 0;
         for (int i = 0; i < n; ++i) {
             (void)hipSetDevice(m->ctx[i]->device);
             if (hipMalloc((void**)&m->dsum[i], n_el * sizeof(float)) != hipSuccess) {
                 m->err = "cannot allocate the per-device radiance sums";
+                return RT_ERR_ALLOC;
+            }
+        }
+        if (!m->use_rccl && n > 1) {
+            (void)hipSetDevice(root->device);
+            if (hipMalloc((void**)&m->stage, n_el * sizeof(float)) != hipSuccess) {
+                m->err = "cannot allocate the staging buffer of the copy-and-add exchange";
                 return RT_ERR_ALLOC;
             }
         }
@@ -1588,9 +1627,10 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
         share[i].spp_offset = p->spp_offset + first;
         if ((rc = check_ready(c)) != RT_OK) return fail_from(c, rc);
         if (count == 0) {  // more devices than samples: this one contributes zeros to the sum
-            if (hipMemsetAsync(m->dsum[i], 0, n_el * sizeof(float), c->stream) != hipSuccess) { m->err = "hipMemsetAsync failed"; return RT_ERR_HIP; }
+            if (hipMemsetAsync(m->dsum[i], 0, n_el * sizeof(float), c->stream) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipMemsetAsync failed");
             continue;
         }
+        // (several entries of one device -- the debug hook -- share that device's GPU but not their workspaces)
         if ((rc = ensure_accum(c, n_el)) != RT_OK) return fail_from(c, rc);
         if ((rc = render_launch(c, cam, &share[i], c->accum, c->rays, m->dsum[i], kFixedToFloat, &launches[i])) != RT_OK)
             return fail_from(c, rc);
@@ -1598,12 +1638,13 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
     rt_multi_stats st;
     std::memset(&st, 0, sizeof(st));
     st.n_devices = (uint32_t)n;
+    st.exchange = m->use_rccl ? 0u : 1u;
     st.samples = (uint64_t)p->width * p->height * p->spp;
     for (int i = 0; i < n; ++i) {
         rt_ctx* c = m->ctx[i];
         if (share[i].spp == 0) {
             (void)hipSetDevice(c->device);
-            if (hipStreamSynchronize(c->stream) != hipSuccess) { m->err = "hipStreamSynchronize failed"; return RT_ERR_HIP; }
+            if (hipStreamSynchronize(c->stream) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipStreamSynchronize failed");
             continue;
         }
         rt_stats s1;
@@ -1612,35 +1653,50 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
         st.kernel_ms = std::max(st.kernel_ms, s1.kernel_ms);
         st.device_kernel_ms[i] = s1.kernel_ms;
     }
-    // 2. the exchange step: one sum-reduce of W*H*3 floats onto ctx[0] (in place on the root)
-    rt_ctx* root = m->ctx[0];
+    // 2. the exchange step: the W*H*3 fp32 sums of every part onto ctx[0] (every render has finished: step 1 waited)
     (void)hipSetDevice(root->device);
-    if (hipEventRecord(root->ev0, root->stream) != hipSuccess) { m->err = "hipEventRecord failed"; return RT_ERR_HIP; }
-    ncclResult_t r = g_rccl.GroupStart();
-    for (int i = 0; i < n && r == ncclSuccess; ++i)
-        r = g_rccl.Reduce(m->dsum[i], m->dsum[i], n_el, ncclFloat, ncclSum, 0, m->comm[i], m->ctx[i]->stream);
-    const ncclResult_t r2 = g_rccl.GroupEnd();
-    if (r == ncclSuccess) r = r2;
-    if (r != ncclSuccess) { m->err = std::string("ncclReduce: ") + g_rccl.GetErrorString(r); return RT_ERR_RCCL; }
+    if (hipEventRecord(root->ev0, root->stream) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipEventRecord failed");
+    if (m->use_rccl) {  // ONE sum-reduce over xGMI, in place on the root
+        ncclResult_t r = g_rccl.GroupStart();
+        for (int i = 0; i < n && r == ncclSuccess; ++i)
+            r = g_rccl.Reduce(m->dsum[i], m->dsum[i], n_el, ncclFloat, ncclSum, 0, m->comm[i], m->ctx[i]->stream);
+        const ncclResult_t r2 = g_rccl.GroupEnd();
+        if (r == ncclSuccess) r = r2;
+        if (r != ncclSuccess) return fail_msg(RT_ERR_RCCL, std::string("ncclReduce: ") + g_rccl.GetErrorString(r));
+    } else {  // no communicator: copy each part to the root device and add it there, in device order
+        for (int i = 1; i < n; ++i) {
+            if (share[i].spp == 0) continue;  // zeros
+            if (hipMemcpyPeerAsync(m->stage, root->device, m->dsum[i], m->ctx[i]->device, n_el * sizeof(float), root->stream) != hipSuccess)
+                return fail_msg(RT_ERR_HIP, "hipMemcpyPeerAsync failed");
+            hipLaunchKernelGGL(add_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, root->stream, m->dsum[0], (const float*)m->stage, n_el);
+            if (hipGetLastError() != hipSuccess) return fail_msg(RT_ERR_HIP, "add_kernel launch failed");
+        }
+    }
     (void)hipSetDevice(root->device);
-    if (hipEventRecord(root->ev1, root->stream) != hipSuccess) { m->err = "hipEventRecord failed"; return RT_ERR_HIP; }
+    if (hipEventRecord(root->ev1, root->stream) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipEventRecord failed");
     // 3. mean over all samples on the root, back to the host
     if (root->out_cap < n_el) {
         if (root->out) (void)hipFree(root->out);
         root->out = nullptr; root->out_cap = 0;
-        if (hipMalloc((void**)&root->out, n_el * sizeof(float)) != hipSuccess) { m->err = "cannot allocate the output image"; return RT_ERR_ALLOC; }
+        if (hipMalloc((void**)&root->out, n_el * sizeof(float)) != hipSuccess) return fail_msg(RT_ERR_ALLOC, "cannot allocate the output image");
         root->out_cap = n_el;
     }
     hipLaunchKernelGGL(scale_kernel, dim3((unsigned)((n_el + 255) / 256)), dim3(256), 0, root->stream, (const float*)m->dsum[0],
                        root->out, n_el, (float)(1.0 / (double)p->spp));
     for (int i = 0; i < n; ++i) {
         (void)hipSetDevice(m->ctx[i]->device);
-        if (hipStreamSynchronize(m->ctx[i]->stream) != hipSuccess) { m->err = "hipStreamSynchronize failed after the reduce"; return RT_ERR_HIP; }
+        if (hipStreamSynchronize(m->ctx[i]->stream) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipStreamSynchronize failed after the exchange step");
     }
     (void)hipSetDevice(root->device);
-    if (hipMemcpy(out_rgb, root->out, n_el * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) { m->err = "hipMemcpy failed"; return RT_ERR_HIP; }
+    if (hipMemcpy(out_rgb, root->out, n_el * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) return fail_msg(RT_ERR_HIP, "hipMemcpy failed");
     (void)hipEventElapsedTime(&st.reduce_ms, root->ev0, root->ev1);
     if (stats) *stats = st;
+    return RT_OK;
+}
+
+int rt_debug_multi(int flags) {
+    if (flags < 0 || flags > 3) return RT_ERR_BAD_ARG;
+    g_multi_debug = flags;
     return RT_OK;
 }
 
