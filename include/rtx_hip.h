@@ -220,11 +220,13 @@ int rt_render(rt_ctx* ctx, const rt_camera* cam, const rt_params* params,
 int rt_render_accum_device(rt_ctx* ctx, const rt_camera* cam, const rt_params* params,
                            float* d_sum_rgb, rt_stats* stats);
 
-/* rt_render_accum_device for callers that CANNOT ALLOCATE (code under HIP graph capture, tight serving loops,
- * harnesses that forbid hipMalloc).  No counterpart in the reference (it has no device, main.rs:64-92 allocates
- * nothing either).  Same arguments, same kernels and bit-identical output, but the fixed-point radiance
- * accumulators and the launch counters live in a static device array inside the library instead of a buffer the
- * ctx hipMallocs on demand, so this entry point calls no hipMalloc / hipFree or other allocating routine.
+/* rt_render_accum_device for callers that CANNOT ALLOCATE (tight serving loops, harnesses that forbid hipMalloc,
+ * code that must not disturb an allocator while a HIP graph is being captured elsewhere).  No counterpart in the
+ * reference (it has no device, main.rs:64-92 allocates nothing either).  Same arguments, same kernels and
+ * bit-identical output, but the fixed-point radiance accumulators and the launch counters live in a static device
+ * array inside the library instead of a buffer the ctx hipMallocs on demand: this entry point allocates no device
+ * or host memory (no hipMalloc / hipFree or other allocating routine).  Like every entry point it runs SYNCHRONOUSLY
+ * on the ctx's own stream and returns after that stream has drained: it is not capturable into a caller's graph.
  * Limit: width*height <= RT_NOALLOC_MAX_PIXELS, larger images return RT_ERR_BAD_ARG.  The array is per GPU, not
  * per ctx, and keeps the previous call's contents (each call clears what it uses): two such calls that overlap
  * on one GPU (two ctxs, two threads) race; calls on different GPUs do not. */

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "../../include/rtx_hip.h"
+#include "scan_layout.h"  // kChunk, kGroup, kLevels, bound_level_*: shared with the device-free layout code
 
 // Census builds (-DRT_CENSUS -S): comments in the ISA that split a pass into regions for tools/isa_census.py
 #ifdef RT_CENSUS
@@ -30,31 +31,16 @@
 
 namespace rtd {
 
-constexpr int kChunk = 16;          // scan lists are padded to a multiple of this (4 groups: one s_load_dwordx16 of bounds)
-#ifndef RT_GROUP
-#define RT_GROUP 4
-#endif
 #ifndef RT_TAILCOND2
 #define RT_TAILCOND2 __builtin_amdgcn_ballot_w64(hit >= 0) != 0
 #endif
 #ifndef RT_TAILCOND
 #define RT_TAILCOND __builtin_expect(__builtin_amdgcn_ballot_w64(any >= 0) != 0, 0)
 #endif
-constexpr int kGroup = RT_GROUP;    // spheres per lazy-root group of the scan (divides kChunk)
 #ifndef RT_SPARSE_RAYS
 #define RT_SPARSE_RAYS 16
 #endif
 constexpr int kSparseRays = RT_SPARSE_RAYS;
-constexpr int kLevels = 5;          // bound levels: groups (4 spheres), then 16, 64, 256, 1024 spheres
-// number of nodes of bound level L for a list of n_chunks chunks, and the level's offset in the bound array
-__host__ __device__ inline int bound_level_count(int n_chunks, int L) {
-    return L == 0 ? n_chunks * (kChunk / RT_GROUP) : (n_chunks + (1 << (2 * (L - 1))) - 1) >> (2 * (L - 1));
-}
-__host__ __device__ inline int bound_level_offset(int n_chunks, int L) {
-    int off = 0;
-    for (int l = 0; l < L; ++l) off += bound_level_count(n_chunks, l);
-    return off;
-}
 constexpr uint32_t kInfBits = 0x7F800000u;
 constexpr float kTwoPow32 = 4294967296.0f;
 
@@ -728,7 +714,6 @@ constexpr float kScanInflate = 1.0f + 8.0f / 16777216.0f;
 //   key <= depth * (1 + kKeyRel) + kKeyEps0 * C        (with room for the roundings of hit_key itself)
 // needs no per-ray term: ScanLists::key_eps0 = kKeyEps0 * C is a scene constant.
 constexpr float kKeyRel = 128.0f / 16777216.0f;
-constexpr float kKeyEps0 = 64.0f / 16777216.0f;
 // The scan does not start at t_min but EARLIER, by kStartShift of t_min plus, along the ray, the keys' absolute
 // error near the scene (half of ScanLists::key_eps0; a distance, so key_eps0 / 2|d| in units of t): a root at or just above t_min
 // (which the reference takes, shape.rs:54 `t_min <= t`) must not come out of the fp32 arithmetic with a negative key
@@ -867,7 +852,6 @@ __device__ __forceinline__ void big_spheres_f64(const SceneT& S, const Ray& ra, 
 // A scene WITHOUT scan lists (upload sends every sphere of a scene of at most kDirectMax spheres besides the big
 // ones to the f64 list: the reference's noise scenes are a ground and one ball): HitList::hit is the f64 loop and the
 // hit record, nothing else -- no scan frame, no nomination, no decision, no retrace.
-constexpr int kDirectMax = 4;
 template <class SceneT>
 __device__ __forceinline__ void closest_direct(const SceneT& S, const Ray& ra, const Ray& rb, bool do_a, bool do_b,
                                                const HitConsts& C, HitRec& ha, HitRec& hb) {

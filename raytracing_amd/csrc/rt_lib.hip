@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rt_device.h"
+#include "scan_layout.h"
 
 using namespace rtd;
 
@@ -29,20 +30,6 @@ constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
 // 1/8 of the) samples of a launch, which are cut into kUnitSppB-sample units so that the waves finish together.
 constexpr uint32_t kUnitSppA = 48, kUnitSppB = 8, kTailSpan = 128;
 constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes are computed in 32 bits)
-// Spheres that take the per-ray f64 test instead of the fp32 scan: those whose radius exceeds kBigRatio times the
-// (lower) median radius of the scene, the kMaxBig largest of them at most.  The scan orders candidates by fp32
-// keys whose absolute error grows with |oc| (~16 ulp of |oc|): a sphere that dwarfs the others (the r = 1000 ground
-// under r = 0.2 balls) has |oc| ~ r for every ray near its surface, and its key error (~1e-3 there) would
-// misorder it against the small spheres resting on it.  The rule is a RATIO, so a scene scaled by any factor is
-// classified the same way (round 1 used r >= 50 or |c| >= 500 in absolute units).
-constexpr float kBigRatio = 32.0f;
-constexpr size_t kMaxBig = 64;
-#ifdef RT_X_NOSLACK
-constexpr double kDirectSlack = 0.0;
-#else
-constexpr double kDirectSlack = 16.0 / 16777216.0;
-#endif  // see nr2_scan in rt_upload_scene
-
 // Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
 // radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
 // per GPU, held until the process ends (24 MiB + 256 B).  In host code this NAME is only a handle for
@@ -753,268 +740,19 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
         }
     }
 
-    std::vector<float4> stat, mov_a, mov_b;
-    std::vector<int32_t> stat_id, mov_id, big_id;
-    std::vector<float> inv_rad(s->n_spheres);
-    for (uint32_t i = 0; i < s->n_spheres; ++i) {
-        if (s->material_id[i] >= s->n_materials) return fail(c, RT_ERR_BAD_ARG, "sphere material_id out of range");
-        const float r = s->radius[i];
-        if (!(r > 0.0f) || !std::isfinite(r)) return fail(c, RT_ERR_BAD_ARG, "sphere radius must be finite and > 0");
-        const float coords[6] = {s->c0x[i], s->c0y[i], s->c0z[i], s->dcx[i], s->dcy[i], s->dcz[i]};
-        for (float v : coords)
-            if (!std::isfinite(v)) return fail(c, RT_ERR_BAD_ARG, "sphere centre / motion must be finite");
-        inv_rad[i] = (float)(1.0 / (double)r);
-    }
-    std::vector<char> is_big(s->n_spheres, 0);
-    if (s->n_spheres > 1) {
-        std::vector<float> sorted_r(s->radius, s->radius + s->n_spheres);
-        std::nth_element(sorted_r.begin(), sorted_r.begin() + (s->n_spheres - 1) / 2, sorted_r.end());
-        const float limit = kBigRatio * sorted_r[(s->n_spheres - 1) / 2];
-        std::vector<uint32_t> cand;
-        for (uint32_t i = 0; i < s->n_spheres; ++i)
-            if (s->radius[i] > limit) cand.push_back(i);
-        if (cand.size() > kMaxBig) {  // keep the largest; the rest ride the scan with coarser tie ordering
-            std::stable_sort(cand.begin(), cand.end(), [&](uint32_t x, uint32_t y) { return s->radius[x] > s->radius[y]; });
-            cand.resize(kMaxBig);
-        }
-        for (uint32_t i : cand) is_big[i] = 1;
-    }
-    // A scene that leaves at most kDirectMax spheres for the scan (the reference's noise scenes: a ground and one ball)
-    // does without it: every sphere goes to the f64 list, which costs ~60 VALU per sphere and pass, where the scan's
-    // frame, walk, nomination and decision cost ~300 before the first sphere (render_kernel's kScan = 2).
+    // the layout of the world for the scan: device-free code (scan_layout.h), tested on the CPU
+    ScanLayout lay;
     {
-        const size_t n_small = (size_t)std::count(is_big.begin(), is_big.end(), 0);
-        if (!c->dbg_no_direct && n_small <= (size_t)kDirectMax && s->n_spheres <= kMaxBig) std::fill(is_big.begin(), is_big.end(), 1);
+        LayoutOptions opt;
+        opt.world_order = c->dbg_world_order; opt.no_planar = c->dbg_no_planar; opt.no_direct = c->dbg_no_direct;
+        std::string lerr;
+        const int lrc = lay.build(s, opt, lerr);
+        if (lrc != RT_OK) return fail(c, lrc, lerr);
     }
-    // The scan frame: centres relative to the middle of the small spheres' bounding box (motion included), so that
-    // the expanded static test (rt_device.h) cancels numbers no larger than the scene itself.
-    double lo3[3] = {0, 0, 0}, hi3[3] = {0, 0, 0};
-    bool any_small = false;
-    for (uint32_t i = 0; i < s->n_spheres; ++i) {
-        if (is_big[i]) continue;
-        const double c0[3] = {s->c0x[i], s->c0y[i], s->c0z[i]}, dc[3] = {s->dcx[i], s->dcy[i], s->dcz[i]};
-        for (int a = 0; a < 3; ++a) {
-            const double v0 = c0[a], v1 = c0[a] + dc[a];
-            if (!any_small) { lo3[a] = std::min(v0, v1); hi3[a] = std::max(v0, v1); }
-            else { lo3[a] = std::min(lo3[a], std::min(v0, v1)); hi3[a] = std::max(hi3[a], std::max(v0, v1)); }
-        }
-        any_small = true;
-    }
-    const float org[3] = {(float)(0.5 * (lo3[0] + hi3[0])), (float)(0.5 * (lo3[1] + hi3[1])), (float)(0.5 * (lo3[2] + hi3[2]))};
-    std::vector<float> stat_nr2;
-    double cmax = 0.0, reach = 0.0;
-    // The planar list (ScanLists::plan): the largest set of static small spheres whose centres share one coordinate
-    // EXACTLY (compared in the scan frame, where the kernel multiplies them), when it has at least kPlanarMin members.
-    // Below that the separate walk costs more than the cheaper tests save (Random, 97 static spheres in y = 0.2:
-    // +1.2 % with the list; configs[1], 480: -8.3 %): the spheres left on the general list still cost a chunk.
-    constexpr size_t kPlanarMin = 160;
-    int plan_axis = 2;
-    float plan_val = 0.0f;
-    std::vector<char> is_planar(s->n_spheres, 0);
-    if (!c->dbg_no_planar) {
-        size_t best = 0;
-        for (int a = 0; a < 3; ++a) {
-            std::vector<float> vals;
-            for (uint32_t i = 0; i < s->n_spheres; ++i) {
-                if (is_big[i] || s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) continue;
-                const float c3[3] = {s->c0x[i], s->c0y[i], s->c0z[i]};
-                vals.push_back((float)((double)c3[a] - org[a]));
-            }
-            std::sort(vals.begin(), vals.end());
-            for (size_t i = 0; i < vals.size();) {
-                size_t j = i;
-                while (j < vals.size() && vals[j] == vals[i]) ++j;
-                if (j - i > best) { best = j - i; plan_axis = a; plan_val = vals[i]; }
-                i = j;
-            }
-        }
-        if (best >= kPlanarMin) {
-            for (uint32_t i = 0; i < s->n_spheres; ++i) {
-                if (is_big[i] || s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) continue;
-                const float c3[3] = {s->c0x[i], s->c0y[i], s->c0z[i]};
-                is_planar[i] = (float)((double)c3[plan_axis] - org[plan_axis]) == plan_val;
-            }
-        } else {
-            plan_val = 0.0f;
-        }
-    }
-    std::vector<float4> plan;
-    std::vector<float> plan_nr2;
-    std::vector<int32_t> plan_id;
-    for (uint32_t i = 0; i < s->n_spheres; ++i) {  // how far from the frame's origin a scan sphere reaches, over its whole motion
-        if (is_big[i]) continue;
-        const double cx = (double)s->c0x[i] - org[0], cy = (double)s->c0y[i] - org[1], cz = (double)s->c0z[i] - org[2];
-        const double ex = cx + s->dcx[i], ey = cy + s->dcy[i], ez = cz + s->dcz[i];
-        reach = std::max(reach, std::max(std::sqrt(cx * cx + cy * cy + cz * cz), std::sqrt(ex * ex + ey * ey + ez * ez)) + (double)s->radius[i]);
-    }
-    // -r^2 as the DIRECT form of the scan's test reads it (rt_device.h: terms_static_direct, terms_moving), widened so
-    // that the test stays conservative where the direction's inflation (kScanInflate, 16 ulp of b^2) cannot help: a
-    // ray that starts next to the sphere and runs tangent to it has b ~ 0, and disc = b^2 - (|oc|^2 - r^2) is then
-    // decided by the roundings of |oc|^2 (a few ulp of r^2) and of centre and origin into the scan frame (2 ulp of
-    // the frame coordinates per component of oc: 8 ulp of r * reach in |oc_perp|^2).  16 ulp of each, twice the bound.
-    // The f64 decision uses the true radius (slot_a); all this costs is a slightly wider band of false nominations.
-    auto nr2_scan = [&](double r) { return (float)-(r * r * (1.0 + kDirectSlack) + kDirectSlack * r * reach); };
-    for (uint32_t i = 0; i < s->n_spheres; ++i) {
-        const double r = s->radius[i];
-        const bool moving = s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f;
-        const double cx = (double)s->c0x[i] - org[0], cy = (double)s->c0y[i] - org[1], cz = (double)s->c0z[i] - org[2];
-        if (is_big[i]) {
-            big_id.push_back((int32_t)i);  // world order (first wins an exact tie, hit.rs:100-110)
-        } else if (moving) {
-            mov_a.push_back(make_float4((float)cx, (float)cy, (float)cz, nr2_scan(r)));
-            mov_b.push_back(make_float4(s->dcx[i], s->dcy[i], s->dcz[i], 0.0f));
-            mov_id.push_back((int32_t)i);
-        } else {
-            // w = |c|^2 - r^2 from the ROUNDED centre the kernel multiplies with, in f64, rounded once
-            const double fx = (float)cx, fy = (float)cy, fz = (float)cz;
-            const float w = (float)(fx * fx + fy * fy + fz * fz - r * r);
-            if (is_planar[i]) {
-                plan.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
-                plan_nr2.push_back(nr2_scan(r));
-                plan_id.push_back((int32_t)i);
-            } else {
-                stat.push_back(make_float4((float)cx, (float)cy, (float)cz, w));
-                stat_nr2.push_back(nr2_scan(r));
-                stat_id.push_back((int32_t)i);
-            }
-            cmax = std::max(cmax, std::sqrt(fx * fx + fy * fy + fz * fz));
-        }
-    }
-    // Order each scan list along a 3-D Morton curve over its centres: the kGroup spheres of a root-extraction
-    // group are then neighbours, so the groups met by a wave's rays are few (rt_device.h, scan_spheres).  Ties in
-    // the curve keep world order (stable sort); rt_debug_set_scan_order keeps the caller's order (A/B switch).
-    if (!c->dbg_world_order) {
-        auto morton_order = [](const std::vector<float4>& ctr) {
-            std::vector<uint32_t> perm(ctr.size());
-            std::iota(perm.begin(), perm.end(), 0u);
-            if (ctr.size() < 2) return perm;
-            float lo[3] = {ctr[0].x, ctr[0].y, ctr[0].z}, hi[3] = {ctr[0].x, ctr[0].y, ctr[0].z};
-            for (const float4& v : ctr) {
-                const float p3[3] = {v.x, v.y, v.z};
-                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], p3[a]); hi[a] = std::fmax(hi[a], p3[a]); }
-            }
-            const float ext = std::fmax(std::fmax(hi[0] - lo[0], hi[1] - lo[1]), std::fmax(hi[2] - lo[2], 1e-30f));
-            auto spread = [](uint64_t v) {  // 21 bits -> every third bit
-                v &= 0x1FFFFF;
-                v = (v | v << 32) & 0x1F00000000FFFFull;
-                v = (v | v << 16) & 0x1F0000FF0000FFull;
-                v = (v | v << 8) & 0x100F00F00F00F00Full;
-                v = (v | v << 4) & 0x10C30C30C30C30C3ull;
-                v = (v | v << 2) & 0x1249249249249249ull;
-                return v;
-            };
-            std::vector<uint64_t> code(ctr.size());
-            for (size_t i = 0; i < ctr.size(); ++i) {
-                const float p3[3] = {ctr[i].x, ctr[i].y, ctr[i].z};
-                uint64_t m = 0;
-                for (int a = 0; a < 3; ++a) {
-                    const double u = ((double)p3[a] - (double)lo[a]) / (double)ext;  // cubic cells: one scale for all axes
-                    m |= spread((uint64_t)std::fmin(std::fmax(u, 0.0) * 2097151.0, 2097151.0)) << a;
-                }
-                code[i] = m;
-            }
-            std::stable_sort(perm.begin(), perm.end(), [&](uint32_t x, uint32_t y) { return code[x] < code[y]; });
-            return perm;
-        };
-        {
-            const std::vector<uint32_t> perm = morton_order(stat);
-            std::vector<float4> s2(stat.size());
-            std::vector<float> r2(stat.size());
-            std::vector<int32_t> i2(stat.size());
-            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = stat[perm[k]]; r2[k] = stat_nr2[perm[k]]; i2[k] = stat_id[perm[k]]; }
-            stat.swap(s2); stat_nr2.swap(r2); stat_id.swap(i2);
-        }
-        {
-            const std::vector<uint32_t> perm = morton_order(plan);
-            std::vector<float4> s2(plan.size());
-            std::vector<float> r2(plan.size());
-            std::vector<int32_t> i2(plan.size());
-            for (size_t k = 0; k < perm.size(); ++k) { s2[k] = plan[perm[k]]; r2[k] = plan_nr2[perm[k]]; i2[k] = plan_id[perm[k]]; }
-            plan.swap(s2); plan_nr2.swap(r2); plan_id.swap(i2);
-        }
-        {
-            const std::vector<uint32_t> perm = morton_order(mov_a);  // by the centre at time 0
-            std::vector<float4> a2(mov_a.size()), b2(mov_a.size());
-            std::vector<int32_t> i2(mov_a.size());
-            for (size_t k = 0; k < perm.size(); ++k) { a2[k] = mov_a[perm[k]]; b2[k] = mov_b[perm[k]]; i2[k] = mov_id[perm[k]]; }
-            mov_a.swap(a2); mov_b.swap(b2); mov_id.swap(i2);
-        }
-    }
-    // pads are never nominated: -r^2 = +inf makes disc = b^2 - inf negative whatever the ray is
-    const float kPad = std::numeric_limits<float>::infinity();
-    while (stat.size() % kChunk) { stat.push_back(make_float4(0, 0, 0, kPad)); stat_nr2.push_back(kPad); stat_id.push_back(-1); }
-    while (plan.size() % kChunk) { plan.push_back(make_float4(0, 0, 0, kPad)); plan_nr2.push_back(kPad); plan_id.push_back(-1); }
-    while (mov_a.size() % kChunk) {
-        mov_a.push_back(make_float4(0, 0, 0, kPad));
-        mov_b.push_back(make_float4(0, 0, 0, 0));
-        mov_id.push_back(-1);
-    }
-    // Bounding spheres for the hierarchical culling (rt_device.h, walk): for every node of every level the sphere
-    // around the member SPHERES it covers (not around child bounds: tighter), in the scan frame, from the rounded
-    // centres the kernel uses; for a moving sphere both ends of its segment c0 .. c0 + dc (a sphere is convex, so the
-    // whole motion for time in [0, 1] is inside).  Centre = the mean of the members' mid-points, radius = the
-    // farthest member surface, widened by 1e-5 relative for the f64 -> fp32 steps.
-    // Which upper levels are worth their tests: a wave's 128 rays leave from a few hit points in all directions, so
-    // a node of radius R at distance D is met by some ray with probability ~ min(1, 16 R^2 / D^2); testing it (12
-    // instructions) instead of its four children (48) pays below ~0.75, i.e. for R < 0.15 X with D ~ 0.7 X and X the
-    // half-diagonal of the small spheres' bounding box.  Measured: the 16-sphere level (R ~ 2.9 of X = 16) LOSES
-    // 12 % on configs[1], all levels together gain 40 % at 16384 spheres.  A ratio, like every threshold here.
-    const double extent = 0.5 * std::sqrt((hi3[0] - lo3[0]) * (hi3[0] - lo3[0]) + (hi3[1] - lo3[1]) * (hi3[1] - lo3[1]) +
-                                          (hi3[2] - lo3[2]) * (hi3[2] - lo3[2]));
-    auto build_bounds = [&](const std::vector<float4>& a, const std::vector<float4>* dcv, const std::vector<float>* nr2v,
-                            const std::vector<int32_t>& ids, int32_t* levels) {
-        *levels = 0;
-        const int n_chunks = (int)(a.size() / kChunk);
-        std::vector<float4> out((size_t)bound_level_offset(n_chunks, kLevels), make_float4(0, 0, 0, kPad));
-        for (int L = 0; L < kLevels; ++L) {
-            const size_t span = L == 0 ? (size_t)kGroup : (size_t)kChunk << (2 * (L - 1));  // spheres per node
-            const int off = bound_level_offset(n_chunks, L), cnt = bound_level_count(n_chunks, L);
-            double r_sum = 0;
-            int r_n = 0;
-            for (int j = 0; j < cnt; ++j) {
-                const size_t lo = (size_t)j * span, hi = std::min(a.size(), lo + span);
-                double cx = 0, cy = 0, cz = 0;
-                int n = 0;
-                for (size_t i = lo; i < hi; ++i) {
-                    if (ids[i] < 0) continue;
-                    const double h = dcv ? 0.5 : 0.0;
-                    cx += a[i].x + (dcv ? h * (*dcv)[i].x : 0.0); cy += a[i].y + (dcv ? h * (*dcv)[i].y : 0.0);
-                    cz += a[i].z + (dcv ? h * (*dcv)[i].z : 0.0);
-                    ++n;
-                }
-                if (n == 0) continue;  // only pads: w = +inf, never met
-                const float bx = (float)(cx / n), by = (float)(cy / n), bz = (float)(cz / n);
-                double R = 0;
-                for (size_t i = lo; i < hi; ++i) {
-                    if (ids[i] < 0) continue;
-                    const double rad = std::sqrt(-(double)(nr2v ? (*nr2v)[i] : a[i].w));
-                    for (int e = 0; e < (dcv ? 2 : 1); ++e) {
-                        const double dx = (double)a[i].x + (dcv ? e * (double)(*dcv)[i].x : 0.0) - bx,
-                                     dy = (double)a[i].y + (dcv ? e * (double)(*dcv)[i].y : 0.0) - by,
-                                     dz = (double)a[i].z + (dcv ? e * (double)(*dcv)[i].z : 0.0) - bz;
-                        R = std::max(R, std::sqrt(dx * dx + dy * dy + dz * dz) + rad);
-                    }
-                }
-                R *= 1.0 + 1e-5;
-                r_sum += R; ++r_n;
-                out[(size_t)off + j] = make_float4(bx, by, bz, (float)((double)bx * bx + (double)by * by + (double)bz * bz - R * R));
-                cmax = std::max(cmax, std::sqrt((double)bx * bx + (double)by * by + (double)bz * bz));
-            }
-            if (L >= 1 && r_n >= 2 && r_sum / r_n < 0.15 * extent) *levels |= 1 << L;
-        }
-        return out;
-    };
-    int32_t stat_levels = 0, mov_levels = 0, plan_levels = 0;
-    const std::vector<float4> stat_bound = build_bounds(stat, nullptr, &stat_nr2, stat_id, &stat_levels);
-    std::vector<float4> plan_bound = build_bounds(plan, nullptr, &plan_nr2, plan_id, &plan_levels);
-    for (float4& b : plan_bound) {  // a bound's centre is the mean of its members': the shared coordinate again, to the bit
-        const float b3[3] = {b.x, b.y, b.z};
-        if (b.w != kPad && b3[plan_axis] != plan_val) return fail(c, RT_ERR_HIP, "internal: planar bound left its plane");
-    }
-    const std::vector<float4> mov_bound = build_bounds(mov_a, &mov_b, nullptr, mov_id, &mov_levels);
-    std::vector<int32_t> scan_id(stat_id);  // scan slots: static, planar, moving (the order the scan walks them)
-    scan_id.insert(scan_id.end(), plan_id.begin(), plan_id.end());
-    scan_id.insert(scan_id.end(), mov_id.begin(), mov_id.end());
+    auto as4 = [](const std::vector<F4>& v) { return reinterpret_cast<const float4*>(v.data()); };
+    const std::vector<F4>&stat = lay.stat, &plan = lay.plan, &mov_a = lay.mov_a, &mov_b = lay.mov_b;
+    const std::vector<int32_t>&scan_id = lay.scan_id, &big_id = lay.big_id;
+    const std::vector<float>& inv_rad = lay.inv_rad;
     const size_t lds_need = lds_scene_bytes((int)fused.size());
     if (lds_need > 64 * 1024) return fail(c, RT_ERR_SCENE_TOO_LARGE, "scene does not fit the 64 KiB LDS budget");
 
@@ -1022,15 +760,15 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     DevScene D{};
     int rc;
 #define UP(expr) if ((rc = (expr)) != RT_OK) { free_scene(c); return rc; }
-    UP(dev_copy(c, stat.data(), stat.size(), &D.lists.stat));
-    UP(dev_copy(c, stat_nr2.data(), stat_nr2.size(), &D.lists.stat_nr2));
-    UP(dev_copy(c, stat_bound.data(), stat_bound.size(), &D.lists.stat_bound));
-    UP(dev_copy(c, mov_bound.data(), mov_bound.size(), &D.lists.mov_bound));
-    UP(dev_copy(c, plan.data(), plan.size(), &D.lists.plan));
-    UP(dev_copy(c, plan_nr2.data(), plan_nr2.size(), &D.lists.plan_nr2));
-    UP(dev_copy(c, plan_bound.data(), plan_bound.size(), &D.lists.plan_bound));
-    UP(dev_copy(c, mov_a.data(), mov_a.size(), &D.lists.mov_a));
-    UP(dev_copy(c, mov_b.data(), mov_b.size(), &D.lists.mov_b));
+    UP(dev_copy(c, as4(stat), stat.size(), &D.lists.stat));
+    UP(dev_copy(c, lay.stat_nr2.data(), lay.stat_nr2.size(), &D.lists.stat_nr2));
+    UP(dev_copy(c, as4(lay.stat_bound), lay.stat_bound.size(), &D.lists.stat_bound));
+    UP(dev_copy(c, as4(lay.mov_bound), lay.mov_bound.size(), &D.lists.mov_bound));
+    UP(dev_copy(c, as4(plan), plan.size(), &D.lists.plan));
+    UP(dev_copy(c, lay.plan_nr2.data(), lay.plan_nr2.size(), &D.lists.plan_nr2));
+    UP(dev_copy(c, as4(lay.plan_bound), lay.plan_bound.size(), &D.lists.plan_bound));
+    UP(dev_copy(c, as4(mov_a), mov_a.size(), &D.lists.mov_a));
+    UP(dev_copy(c, as4(mov_b), mov_b.size(), &D.lists.mov_b));
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
     std::vector<BigSphere> big(big_id.size());
@@ -1080,34 +818,27 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, texs.data(), texs.size(), &D.texs));
     UP(dev_copy(c, fused.data(), fused.size(), &D.fused));
 #undef UP
-    D.lists.ox = org[0]; D.lists.oy = org[1]; D.lists.oz = org[2];
-    D.lists.cmax = (float)(cmax * (1.0 + 1e-6));
-    D.lists.key_eps0 = (float)(reach * (1.0 + 1e-6)) * kKeyEps0;
-    D.lists.stat_levels = stat_levels; D.lists.mov_levels = mov_levels;
-    D.lists.mov_axes = 0;
-    for (const float4& v : mov_b) D.lists.mov_axes |= (v.x != 0.0f ? 1 : 0) | (v.y != 0.0f ? 2 : 0) | (v.z != 0.0f ? 4 : 0);
-    auto sparse_levels = [](size_t n_spheres) {
-        int32_t m = 0;
-        for (int L = 1; L < kLevels; ++L)
-            if (bound_level_count((int)(n_spheres / kChunk), L) >= 2) m |= 1 << L;
-        return m;
-    };
-    D.lists.np_pad = (int32_t)plan.size();
-    c->scan_mode = (stat.empty() && plan.empty() && mov_a.empty()) ? 2 : !plan.empty() ? 1 : 0;
-    D.lists.plan_axis = plan_axis;
-    D.lists.plan_val = plan_val;
-    D.lists.plan_levels = plan_levels;
-    D.lists.plan_levels_sparse = plan_levels | sparse_levels(plan.size());
-    D.lists.stat_levels_sparse = stat_levels | sparse_levels(stat.size());
-    D.lists.mov_levels_sparse = mov_levels | sparse_levels(mov_a.size());
+    D.lists.ox = lay.org[0]; D.lists.oy = lay.org[1]; D.lists.oz = lay.org[2];
+    D.lists.cmax = lay.cmax;
+    D.lists.key_eps0 = lay.key_eps0;
+    D.lists.stat_levels = lay.stat_levels;
+    D.lists.mov_levels = lay.mov_levels;
+    D.lists.plan_levels = lay.plan_levels;
+    D.lists.stat_levels_sparse = lay.stat_levels_sparse;
+    D.lists.mov_levels_sparse = lay.mov_levels_sparse;
+    D.lists.plan_levels_sparse = lay.plan_levels_sparse;
+    D.lists.mov_axes = lay.mov_axes;
+    D.lists.plan_axis = lay.plan_axis;
+    D.lists.plan_val = lay.plan_val;
     D.lists.ns_pad = (int32_t)stat.size();
+    D.lists.np_pad = (int32_t)plan.size();
     D.lists.nm_pad = (int32_t)mov_a.size();
+    c->scan_mode = (stat.empty() && plan.empty() && mov_a.empty()) ? 2 : !plan.empty() ? 1 : 0;
     D.n_big = (int32_t)big_id.size();
     D.n_fused = (int32_t)fused.size();
     D.n_spheres = (int32_t)s->n_spheres;
     D.n_textures = (int32_t)s->n_textures;
-    D.any_moving = 0;
-    for (uint32_t i = 0; i < s->n_spheres; ++i) D.any_moving |= (s->dcx[i] != 0.0f || s->dcy[i] != 0.0f || s->dcz[i] != 0.0f) ? 1 : 0;
+    D.any_moving = lay.any_moving;
     c->S = D;
     c->lds_scene = align16(lds_need);
     c->has_noise = false;

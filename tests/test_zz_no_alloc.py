@@ -24,6 +24,35 @@ def _both(ctx, api, torch, w, W, H, spp, **kw):
     return b
 
 
+def test_noalloc_entry_allocates_no_device_memory(api):
+    """On a FRESH context, before the allocating twin has ever run on it (so nothing of the render has been allocated
+    or warmed up on its behalf): the device's free memory (hipMemGetInfo through torch.cuda.mem_get_info) is the same
+    after the call as before it, while the allocating twin then takes W*H*3 u64 accumulators from it."""
+    import torch
+    ctx = api.Context(0)
+    try:
+        w = api.World("FinalStatic", seed=1, aspect=640 / 400)
+        ctx.upload(w.scene)
+        W, H = 640, 400
+        p = api.make_params(W, H, 4, seed=w.render_seed)
+        out = torch.zeros(H, W, 3, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
+        free0, _ = torch.cuda.mem_get_info(0)
+        st = ctx.render_accum_device_noalloc(w.camera, p, out.data_ptr())
+        free1, _ = torch.cuda.mem_get_info(0)
+        assert st.samples == W * H * 4 and out.sum().item() > 0
+        assert free1 == free0, (free0, free1)
+        ref = torch.zeros_like(out)
+        torch.cuda.synchronize()
+        free2, _ = torch.cuda.mem_get_info(0)
+        ctx.render_accum_device(w.camera, p, ref.data_ptr())
+        free3, _ = torch.cuda.mem_get_info(0)
+        assert torch.equal(out, ref)
+        assert free2 - free3 >= W * H * 3 * 8 // 2, (free2, free3)  # (the allocator rounds: at least half of 6.1 MB shows)
+    finally:
+        ctx.close()
+
+
 def test_noalloc_entry_matches_the_allocating_one(api):
     import torch
     ctx = api.Context(0)  # a context of its own: passes alone in a fresh process and after the other tests
