@@ -80,9 +80,42 @@ def roofline_of(model, rays, samples, kernel_ms, launches, layout):
     kernel = "render_kernel<%s, %s, %d>" % (b(layout["noise"]), b(layout["tile_buffers"] == 2), layout.get("scan", 0))
     return {"bound": "valu", "kernel": kernel,
             "achieved": achieved, "peak": FP32_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP32_VALU_PEAK_TFLOPS, "flops_per_ray": model["flops_per_ray"],
+            "frac": achieved / FP32_VALU_PEAK_TFLOPS,
+            "frac_means": "time-to-solution against a FLAT-LIST scan at fp32 VALU peak: algorithmic flops (every sphere "
+                          "tested for every ray segment, as hit.rs:100-110 does: flops_per_ray x rays) / kernel time / peak. "
+                          "NOT VALU utilisation: the kernel culls ~2/3 of those tests, so it executes fewer flops than it is "
+                          "credited with (this figure can pass 1.0); see executed_frac and valu_* for what is issued",
+            "flops_per_ray": model["flops_per_ray"],
             "flops_per_noise_hit": model["flops_per_noise_hit"],
             "kernel_ms_per_launch": kernel_ms / max(launches, 1)}
+
+
+SHADER_CLOCK_HZ, N_SIMD = 2.4e9, 1024  # MI355X_MICROARCH.md: 256 CUs x 4 SIMDs at 2.4 GHz
+
+
+def executed_work(scene, width, height, spp, kernel_ms_per_launch):
+    """What the kernel EXECUTES, next to the algorithmic figure: from the committed PMC pass of this workload
+    (profiles/valu_pmc.json, written by tools/summarize_prof.py), None when it was measured for other arguments.
+    executed_frac is an UPPER bound of the fp32 rate actually issued: every VALU wave-instruction priced as a packed
+    FMA (256 flop) over the measured share of active lanes, against the live kernel time."""
+    try:
+        t = json.load(open(os.path.join(ROOT, "profiles", "valu_pmc.json")))
+    except Exception:
+        return None
+    for e in t.get("entries", []):
+        c = e.get("config", {})
+        if (c.get("scene"), c.get("width"), c.get("height"), c.get("spp")) == (scene, width, height, spp):
+            insts = e["valu_insts_per_launch"]
+            lane = e["thread_cycles_valu"] / (64.0 * e["active_inst_valu"])
+            sec = kernel_ms_per_launch * 1e-3
+            upper = insts * 256.0 * lane / sec / 1e12
+            return {"valu_insts_per_launch": insts,
+                    "valu_cycles_per_inst_per_simd": sec * SHADER_CLOCK_HZ * N_SIMD / insts,
+                    "valu_lane_util": lane,
+                    "executed_tflops_upper_bound": upper,
+                    "executed_frac": upper / FP32_VALU_PEAK_TFLOPS,
+                    "pmc_source": e.get("source")}
+    return None
 
 
 def measured_traffic(scene, width, height, spp):
@@ -203,6 +236,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    # the headline step's image (outside the timed region): every pixel finite, and the mean in [0, 1] as the
+    # reference's encode demands (screen.rs:31-34); acc holds per-pixel SUMS over this rank's `count` samples
+    headline_finite = bool(torch.isfinite(acc).all().item())
+    headline_in_unit_range = bool(((acc >= 0) & (acc <= float(count) * (1.0 + 1e-6))).all().item())
     samples_per_step = args.width * args.height * total_spp
     rays = sum(int(s.rays_traced) for s in stats)
     samples_rank = sum(int(s.samples) for s in stats)
@@ -219,6 +256,9 @@ def main():
         traffic = measured_traffic(args.scene, args.width, args.height, count)
         roof["traffic"] = traffic  # HBM bytes per launch, PMC passes of THIS workload (profiles/), else null
         roof["traffic_frac_of_hbm_peak"] = (traffic / (roof["kernel_ms_per_launch"] * 1e-3) / 8e12) if traffic else None
+        ex = executed_work(args.scene, args.width, args.height, count, roof["kernel_ms_per_launch"])
+        roof.update(ex or {"valu_insts_per_launch": None, "valu_cycles_per_inst_per_simd": None, "valu_lane_util": None,
+                           "executed_tflops_upper_bound": None, "executed_frac": None, "pmc_source": None})
         roof["launches_per_step"] = launches / args.steps
         if strong:
             workload = (f"configs[4]: RTIOW final scene (static, {model['n_static'] + model['n_moving']} spheres) "
@@ -251,7 +291,8 @@ def main():
             },
             "mrays_per_s": rays_total / dt / 1e6,
             "rays_per_sample": rays / samples_rank,
-            "fp32_peak_frac": roof["frac"],
+            "all_finite": headline_finite, "in_unit_range": headline_in_unit_range,
+            "fp32_peak_frac": roof["frac"],  # = roofline.frac: algorithmic (flat-list) flops / time / peak, see roofline.frac_means
             "roofline": roof,
             "library": api.lib_provenance(),  # the file that ran: absolute path, sha256, whether it is the in-tree build
         }
@@ -293,6 +334,7 @@ def extra_configs(api, torch, ctx, dev, runs=3):
         roof = roofline_of(model, int(st.rays_traced), int(st.samples), float(st.kernel_ms), int(st.n_launches),
                            layout_of(ctx, model))
         roof["traffic"] = measured_traffic(scene, W, H, spp)
+        roof.update(executed_work(scene, W, H, spp, roof["kernel_ms_per_launch"]) or {})
         res.append({
             "config": tag, "scene": scene, "width": W, "height": H, "spp": spp, "spp_offset": off,
             "n_static": model["n_static"], "n_moving": model["n_moving"],

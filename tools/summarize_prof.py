@@ -58,6 +58,27 @@ def main():
         entries.append({"config": cfg, "bytes_per_launch": fetch + write, "fetch_bytes": fetch, "write_bytes": write,
                         "source": os.path.basename(src)})
         json.dump({"entries": entries}, open(tpath, "w"), indent=1)
+    if "SQ_INSTS_VALU" in counters and "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
+        # one entry per measured workload (like hbm_traffic.json): bench.py quotes the executed-work figures of the
+        # entry whose config matches its arguments
+        vpath = os.path.join(os.path.dirname(dst), "valu_pmc.json")
+        try:
+            ventries = json.load(open(vpath)).get("entries", [])
+        except Exception:
+            ventries = []
+        cfg = {}
+        if os.path.exists(bench):
+            c = json.loads(open(bench).read().strip().splitlines()[-1])["config"]
+            cfg = {"scene": c["scene"], "width": c["width"], "height": c["height"], "spp": c["spp_per_gpu"]}
+        ventries = [e for e in ventries if e.get("config") != cfg]
+        ventries.append({"config": cfg, "source": os.path.basename(src),
+                         "valu_insts_per_launch": counters["SQ_INSTS_VALU"],
+                         "active_inst_valu": counters["SQ_ACTIVE_INST_VALU"],
+                         "thread_cycles_valu": counters["SQ_THREAD_CYCLES_VALU"],
+                         "salu_insts_per_launch": counters.get("SQ_INSTS_SALU"),
+                         "smem_insts_per_launch": counters.get("SQ_INSTS_SMEM"),
+                         "waves": counters.get("SQ_WAVES")})
+        json.dump({"entries": ventries}, open(vpath, "w"), indent=1)
     if "SQ_THREAD_CYCLES_VALU" in counters and "SQ_ACTIVE_INST_VALU" in counters:
         derived.append("VALU lane utilisation (SQ_THREAD_CYCLES_VALU / (64 * SQ_ACTIVE_INST_VALU)): "
                        f"{counters['SQ_THREAD_CYCLES_VALU'] / (64 * counters['SQ_ACTIVE_INST_VALU']):.3f}")
