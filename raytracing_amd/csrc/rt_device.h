@@ -391,10 +391,9 @@ struct Floor {
 // (v_med3_u32 keeps best <= second).  hit_end compares it with the exact (f64) depth of the accepted nominee: when
 // some other candidate's key does not lie safely beyond it, the ray is traced again from that nominee on and the next
 // candidate is decided in f64 as well, so near-ties are ordered by their f64 depths, not by fp32 keys.
-template <bool kFloor>
-__device__ __forceinline__ void take_root(float b, float disc, int slot, int lo, int ls, uint32_t& best, uint32_t& second,
-                                          int& idx) {
-    const float s = __builtin_amdgcn_sqrtf(disc);  // NaN for disc < 0: loses the unsigned compare
+// The float part (two roots and the median) is packed for the two rays of a lane; the integer part is per ray.
+__device__ __forceinline__ f2 root_keys2(f2 b, f2 disc) {
+    const f2 s = f2{__builtin_amdgcn_sqrtf(disc.x), __builtin_amdgcn_sqrtf(disc.y)};  // NaN for disc < 0
     // A key must be a LOWER bound of the exact depth (hit_end stops looking once the next key exceeds the exact best).
     // The near root b - s is one (the inflated direction and the widened radius both lower it); the far root b + s is
     // not -- the widened radius raises it, by far more than the keys' error bound when the ray runs tangent just inside
@@ -402,11 +401,16 @@ __device__ __forceinline__ void take_root(float b, float disc, int slot, int lo,
     // the median of (b - s, b + s, z) with z = disc * 0 (+0, or -0 when disc < 0) is the near root when that is ahead,
     // +0 when only the far root is, and the (negative: loses as an unsigned pattern) far root when both are behind;
     // for disc < 0 the two roots are NaNs, v_med3_f32 then returns the minimum of its non-NaN operands: -0, which loses.
+    const f2 k1 = b - s, k2 = b + s, z = disc * splat2(0.0f);
 #ifdef RT_X_OLDKEY
-    uint32_t key = min(__float_as_uint(b - s), __float_as_uint(b + s));
+    return f2{__uint_as_float(min(__float_as_uint(k1.x), __float_as_uint(k2.x))), __uint_as_float(min(__float_as_uint(k1.y), __float_as_uint(k2.y)))};
 #else
-    uint32_t key = __float_as_uint(__builtin_amdgcn_fmed3f(b - s, b + s, disc * 0.0f));
+    return f2{__builtin_amdgcn_fmed3f(k1.x, k2.x, z.x), __builtin_amdgcn_fmed3f(k1.y, k2.y, z.y)};
 #endif
+}
+template <bool kFloor>
+__device__ __forceinline__ void take_root(float key_f, int slot, int lo, int ls, uint32_t& best, uint32_t& second, int& idx) {
+    uint32_t key = __float_as_uint(key_f);
     if (kFloor) key = ((int)key > lo - (slot > ls ? 1 : 0)) ? key : 0xFFFFFFFFu;  // at or before the floor: decided already
 #ifndef RT_X_NOSECOND
     second = max(min(key, best), min(max(key, best), second));  // v_med3_u32
@@ -438,8 +442,9 @@ __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direc
             direct(k, b, disc);
             RT_STAT(2, 1);
             RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc.x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc.y >= 0)));
-            take_root<kFloor>(b.x, disc.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, second_a, idx_a);
-            take_root<kFloor>(b.y, disc.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, second_b, idx_b);
+            const f2 key = root_keys2(b, disc);
+            take_root<kFloor>(key.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, second_a, idx_a);
+            take_root<kFloor>(key.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, second_b, idx_b);
         }
     }
 }

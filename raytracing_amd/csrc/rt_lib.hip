@@ -264,10 +264,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             ps[1].thr = ps[1].thr * v1;
         }
         RT_MARK("loopctl");
-        if (__ballot(ps[0].alive || ps[1].alive) == 0ull) {
-            if (!more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
-            continue;          // (next >= total here, so the next pass claims a unit or clears `more`)
-        }
+        const bool any_alive = __ballot(ps[0].alive || ps[1].alive) != 0ull;
+        if (!any_alive && !more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
+        if (any_alive) {  // (else next >= total here, so the next pass claims a unit or clears `more`)
 
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
         if constexpr (kDirect) {
@@ -358,6 +357,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 }
             }
         }
+        }  // any_alive
     }
     // the last tile (the final claim made it the previous one); the current buffer is empty unless the loop is ever left with a tile open
     if (kTwoBufs) flush_tile(kTileAcc - cur_off, __builtin_amdgcn_readfirstlane(prev_geo[0]), __builtin_amdgcn_readfirstlane(prev_geo[1]),
