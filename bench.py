@@ -239,7 +239,8 @@ def main():
     # the headline step's image (outside the timed region): every pixel finite, and the mean in [0, 1] as the
     # reference's encode demands (screen.rs:31-34); acc holds per-pixel SUMS over this rank's `count` samples
     headline_finite = bool(torch.isfinite(acc).all().item())
-    headline_in_unit_range = bool(((acc >= 0) & (acc <= float(count) * (1.0 + 1e-6))).all().item())
+    # (on rank 0 of an N-rank job the reduce has summed all ranks' samples into acc: total_spp of them)
+    headline_in_unit_range = bool(((acc >= 0) & (acc <= float(total_spp if rank == 0 else count) * (1.0 + 1e-6))).all().item())
     samples_per_step = args.width * args.height * total_spp
     rays = sum(int(s.rays_traced) for s in stats)
     samples_rank = sum(int(s.samples) for s in stats)

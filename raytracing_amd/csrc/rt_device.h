@@ -91,6 +91,7 @@ struct ScanLists {
     int32_t plan_levels, plan_levels_sparse;
     const float4* mov_a;    // nm_pad x {c0x, c0y, c0z, -r^2}; pads -r^2 = +inf
     const float4* mov_b;    // nm_pad x {dcx, dcy, dcz, 0}
+    const float* mov_dy;    // nm_pad x dcy: all the "y only" walk reads of the motion (one s_load_dwordx4 per group instead of a dwordx16)
     const float4* mov_bound;  // the same levels for the moving list, over the whole motion for time in [0, 1]
     int32_t ns_pad, nm_pad;
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
@@ -609,9 +610,12 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             const int base = g * kGroup;
             f2 b[kGroup], q[kGroup], disc[kGroup];
             int any = (int)0x80000000;
+            v4f dy = {0, 0, 0, 0};
+            if constexpr (kAxes == 2) dy = *(cv4p)(uintptr_t)(S.mov_dy + base);
 #pragma unroll
             for (int k = 0; k < kGroup; ++k) {
-                terms_moving<kAxes>(ma[base + k], mb[base + k], r, b[k], q[k]);
+                if constexpr (kAxes == 2) terms_moving<kAxes>(ma[base + k], v4f{0.0f, dy[k], 0.0f, 0.0f}, r, b[k], q[k]);
+                else terms_moving<kAxes>(ma[base + k], mb[base + k], r, b[k], q[k]);
                 disc[k] = fma2(b[k], b[k], -q[k]);
                 any = max(max(any, __float_as_int(disc[k].x)), __float_as_int(disc[k].y));
             }

@@ -298,6 +298,7 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 L.ns_pad = K->S.lists.ns_pad;
                 L.mov_a = K->S.lists.mov_a;
                 L.mov_b = K->S.lists.mov_b;
+                L.mov_dy = K->S.lists.mov_dy;
                 L.mov_bound = K->S.lists.mov_bound;
                 L.mov_levels = sparse_pass ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels;
                 L.mov_axes = K->S.lists.mov_axes;
@@ -769,6 +770,11 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     UP(dev_copy(c, as4(lay.plan_bound), lay.plan_bound.size(), &D.lists.plan_bound));
     UP(dev_copy(c, as4(mov_a), mov_a.size(), &D.lists.mov_a));
     UP(dev_copy(c, as4(mov_b), mov_b.size(), &D.lists.mov_b));
+    {
+        std::vector<float> mov_dy(mov_b.size());
+        for (size_t k = 0; k < mov_b.size(); ++k) mov_dy[k] = mov_b[k].y;
+        UP(dev_copy(c, mov_dy.data(), mov_dy.size(), &D.lists.mov_dy));
+    }
     UP(dev_copy(c, scan_id.data(), scan_id.size(), &D.scan_id));
     UP(dev_copy(c, big_id.data(), big_id.size(), &D.big_id));
     std::vector<BigSphere> big(big_id.size());
