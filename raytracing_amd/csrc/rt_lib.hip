@@ -82,6 +82,20 @@ constexpr uint32_t kTileAcc = kTile * kTile * 3;  // u64 sums of one tile
 constexpr uint32_t kOrphan = 0xFFFFFFFFu;         // PathState::acc_idx of a path whose tile buffer was retired: global atomics
 // dynamic LDS after the noise tables, per wave: acc_bufs tile buffers, then the previous tile's geometry (4 words)
 __host__ __device__ inline size_t wave_lds_bytes(uint32_t acc_bufs) { return (size_t)acc_bufs * kTileAcc * sizeof(unsigned long long) + 16; }
+// EXPERIMENT (-DRT_X_REGROUP=K, not in the product build; DESIGN.md 7, tools/regroup_ab.sh): every K passes the four
+// waves of a workgroup re-deal their 512 path slots through LDS, sorted by (direction octant, origin quadrant), dead
+// slots last, so that the 128 rays of a wave meet fewer bounds (hit.rs:264-283 culls per ray).  LDS after the waves'
+// tile buffers: two sets of 64 bin counters, two sets of four `more` flags, then 19 words per slot (14 of path state,
+// 5 of an unfinished trace's record).
+#ifdef RT_X_REGROUP
+constexpr uint32_t kRgSlots = kBlock * 2, kRgWords = 14, kRgRetryWords = 5;
+constexpr size_t kRegroupBytes = (128 + 8 + (size_t)(kRgWords + kRgRetryWords) * kRgSlots) * 4;
+#else
+constexpr size_t kRegroupBytes = 0;
+#endif
+__host__ __device__ inline size_t block_lds_bytes(size_t scene_bytes, uint32_t acc_bufs, bool regroups) {
+    return scene_bytes + (size_t)kWavesPerBlock * wave_lds_bytes(acc_bufs) + (regroups ? kRegroupBytes : 0);
+}
 
 #ifndef RT_WAVES_PER_EU
 #define RT_WAVES_PER_EU 3  // 168 VGPRs.  Four waves per SIMD (128 VGPRs) spill ~60 dwords per lane and measure +1 %; two
@@ -109,6 +123,18 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
     uint32_t* prev_geo = reinterpret_cast<uint32_t*>(acc + kBufs * kTileAcc);  // {tx0, ty0, tw, npix} of the previous tile
     for (uint32_t e = lane; e < kBufs * kTileAcc; e += 64) acc[e] = 0;
     if (lane < 4) prev_geo[lane] = lane == 2 ? 1u : 0u;
+#ifdef RT_X_REGROUP
+    constexpr bool kRegroup = !kNoise && !kDirect;
+    uint32_t* const rg = reinterpret_cast<uint32_t*>(lds + A.lds_scene_bytes + kWavesPerBlock * wave_lds_bytes(kBufs));
+    uint32_t* const rg_stage = rg + 136;
+    uint32_t rg_pass = 0, rg_round = 0;
+    if (kRegroup) {
+        if (tid < 136) rg[tid] = 0;
+        __syncthreads();
+    }
+#else
+    constexpr bool kRegroup = false;
+#endif
 
     // current unit (wave-uniform); cur_off: the current tile's buffer (the previous tile's is the other one)
     uint32_t tx0 = 0, ty0 = 0, tw = 1, npix = 0, s_lo = 0;
@@ -263,9 +289,89 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             ps[0].thr = ps[0].thr * v0;  // colour = white * value (material.rs:369-373, :529-533)
             ps[1].thr = ps[1].thr * v1;
         }
+#ifdef RT_X_REGROUP
+        if (kRegroup && ++rg_pass == (uint32_t)(RT_X_REGROUP)) {
+            // every wave of the workgroup comes here after the same number of passes (a wave with nothing to do keeps
+            // looping) and all of them leave the loop together below: the barriers always meet four waves
+            rg_pass = 0;
+            const uint32_t par = rg_round & 1u;
+            ++rg_round;
+            uint32_t* const cnt = rg + par * 64;
+            uint32_t* const flg = rg + 128 + par * 4;
+            const ArgsPtr K = launder(K0);
+            const float cx = (float)K->hc.ox, cz = (float)K->hc.oz;
+            uint32_t key[2], rank[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const Ray& r = ps[s].ray;
+#ifdef RT_X_REGROUP_NOKEY  // the exchange without the sort (one bin for every live path): what the machinery alone costs
+                key[s] = !ps[s].alive ? 32u : 0u; (void)r; (void)cx; (void)cz;
+                if (true) { rank[s] = atomicAdd(&cnt[key[s]], 1u); continue; }
+#endif
+                key[s] = !ps[s].alive ? 32u
+                         : (r.d.x > 0.0f ? 1u : 0u) | (r.d.y > 0.0f ? 2u : 0u) | (r.d.z > 0.0f ? 4u : 0u) |
+                           (r.o.x > cx ? 8u : 0u) | (r.o.z > cz ? 16u : 0u);
+                rank[s] = atomicAdd(&cnt[key[s]], 1u);
+            }
+            if (lane == 0) flg[wave] = more ? 1u : 0u;
+            __syncthreads();
+            const uint32_t mine = lane < 33 ? cnt[lane] : 0u;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const uint32_t t = __shfl_up(incl, off, 64);
+                if (lane >= off) incl += t;
+            }
+            const uint32_t excl = incl - mine;
+            const uint32_t n_live = __shfl(excl, 32, 64);
+            const bool any_more = (flg[0] | flg[1] | flg[2] | flg[3]) != 0u;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                PathState& P = ps[s];
+                const uint32_t pos = __shfl(excl, (int)key[s], 64) + rank[s];
+                const bool retry = P.alive && h[s].sphere == kRetry;
+                uint32_t* const st = rg_stage + pos;
+                st[0 * kRgSlots] = __float_as_uint(P.ray.o.x); st[1 * kRgSlots] = __float_as_uint(P.ray.o.y); st[2 * kRgSlots] = __float_as_uint(P.ray.o.z);
+                st[3 * kRgSlots] = __float_as_uint(P.ray.d.x); st[4 * kRgSlots] = __float_as_uint(P.ray.d.y); st[5 * kRgSlots] = __float_as_uint(P.ray.d.z);
+                st[6 * kRgSlots] = __float_as_uint(P.ray.time);
+                st[7 * kRgSlots] = __float_as_uint(P.thr.x); st[8 * kRgSlots] = __float_as_uint(P.thr.y); st[9 * kRgSlots] = __float_as_uint(P.thr.z);
+                st[10 * kRgSlots] = P.pix; st[11 * kRgSlots] = P.smp;
+                st[12 * kRgSlots] = P.depth | (P.alive ? 0x80000000u : 0u) | (retry ? 0x40000000u : 0u);
+                st[13 * kRgSlots] = (P.acc_idx == kOrphan ? 0x3FFu : P.acc_idx) | ((uint32_t)wave << 10);
+                if (retry) {
+                    st[14 * kRgSlots] = (uint32_t)h[s].front; st[15 * kRgSlots] = __float_as_uint(h[s].t);
+                    st[16 * kRgSlots] = __float_as_uint(h[s].p.x); st[17 * kRgSlots] = __float_as_uint(h[s].p.y); st[18 * kRgSlots] = __float_as_uint(h[s].p.z);
+                }
+            }
+            __syncthreads();
+            if (tid < 64) cnt[tid] = 0;  // this set is used again two rounds on, after the two barriers of the next round
+            if (n_live == 0 && !any_more) break;  // the same values in all four waves: the workgroup leaves together
+            if (rg_round > (1u << 24)) break;      // (never reached; also the same in all four waves)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                PathState& P = ps[s];
+                const uint32_t* const st = rg_stage + (uint32_t)wave * 128u + (uint32_t)s * 64u + (uint32_t)lane;
+                P.ray.o = {__uint_as_float(st[0 * kRgSlots]), __uint_as_float(st[1 * kRgSlots]), __uint_as_float(st[2 * kRgSlots])};
+                P.ray.d = {__uint_as_float(st[3 * kRgSlots]), __uint_as_float(st[4 * kRgSlots]), __uint_as_float(st[5 * kRgSlots])};
+                P.ray.time = __uint_as_float(st[6 * kRgSlots]);
+                P.thr = {__uint_as_float(st[7 * kRgSlots]), __uint_as_float(st[8 * kRgSlots]), __uint_as_float(st[9 * kRgSlots])};
+                P.pix = st[10 * kRgSlots]; P.smp = st[11 * kRgSlots];
+                const uint32_t a = st[12 * kRgSlots], b = st[13 * kRgSlots];
+                P.depth = a & 0x3FFFFFFFu;
+                P.alive = (a & 0x80000000u) != 0u;
+                const bool retry = (a & 0x40000000u) != 0u;
+                P.acc_idx = ((b >> 10) == (uint32_t)wave && (b & 0x3FFu) != 0x3FFu) ? (b & 0x3FFu) : kOrphan;  // another wave's tile buffer: global sums
+                h[s].sphere = retry ? kRetry : -1;
+                if (retry) {
+                    h[s].front = (int32_t)st[14 * kRgSlots]; h[s].t = __uint_as_float(st[15 * kRgSlots]);
+                    h[s].p = {__uint_as_float(st[16 * kRgSlots]), __uint_as_float(st[17 * kRgSlots]), __uint_as_float(st[18 * kRgSlots])};
+                }
+            }
+        }
+#endif
         RT_MARK("loopctl");
         const bool any_alive = __ballot(ps[0].alive || ps[1].alive) != 0ull;
-        if (!any_alive && !more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
+        if (!kRegroup && !any_alive && !more) break;  // unit queue empty and every path finished: the only exit, reached by every wave
         if (any_alive) {  // (else next >= total here, so the next pass claims a unit or clears `more`)
 
         // ---- one ray segment per live path: closest hit (both paths in one packed scan)
@@ -854,13 +960,17 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     // noise tables or would cost a resident workgroup
     int occ[3] = {0, 0, 0};
     for (uint32_t bufs = 1; bufs <= 2; ++bufs) {
-        const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(bufs);
+        const size_t lds_bytes = block_lds_bytes(c->lds_scene, bufs, !c->has_noise && c->scan_mode != 2);
         if (lds_bytes > 65536) continue;
         RT_HIP(c, hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ[bufs], render_variant(c->has_noise, bufs == 2, c->scan_mode), kBlock, lds_bytes));
     }
     c->acc_bufs = (occ[2] >= occ[1] && occ[2] > 0) ? 2 : 1;
     if (c->dbg_tile_bufs && occ[c->dbg_tile_bufs] > 0) c->acc_bufs = (uint32_t)c->dbg_tile_bufs;  // rt_debug_set_tile_buffers
     c->blocks_per_cu = occ[c->acc_bufs];
+#ifdef RT_X_REGROUP
+    fprintf(stderr, "RT_X_REGROUP=%d: %d workgroups per CU, %zu bytes of LDS each\n", (int)(RT_X_REGROUP), c->blocks_per_cu,
+            block_lds_bytes(c->lds_scene, c->acc_bufs, !c->has_noise && c->scan_mode != 2));
+#endif
     c->has_scene = true;
     return RT_OK;
 }
@@ -907,7 +1017,7 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
     A.acc_bufs = c->acc_bufs;
     A.accum = accum;
     A.rays = counters;
-    const size_t lds_bytes = c->lds_scene + (size_t)kWavesPerBlock * wave_lds_bytes(c->acc_bufs);
+    const size_t lds_bytes = block_lds_bytes(c->lds_scene, c->acc_bufs, !c->has_noise && c->scan_mode != 2);
 
     // Launch plan.  A launch renders `spp_l` samples per pixel as n_tiles * n_levels work units that a grid of
     // persistent waves (as many as the GPU holds at once) pulls from a counter.  Launches are capped at 2^31
