@@ -97,7 +97,6 @@ struct ScanLists {
     float ox, oy, oz;       // origin of the scan frame (world coordinates)
     float cmax;             // max |c| over the static list, in the scan frame
     float key_eps0;         // absolute part of a key's error bound: kKeyEps0 * max(|c| + r) over the scan lists (scan frame)
-    float far_slack;        // how far above its exact value a far root's fp32 value can lie (root_keys2; ScanLayout::far_slack)
     int32_t mov_axes;       // bit k set: some moving sphere has dc[k] != 0 (terms_moving skips the other axes)
     int32_t stat_levels, mov_levels;  // bit L >= 1 set: bound level L is worth testing for this list (upload decides)
     // the same for a wave with at most kSparseRays live rays (the end of a launch, when the last long paths are traced
@@ -394,31 +393,20 @@ struct Floor {
 // some other candidate's key does not lie safely beyond it, the ray is traced again from that nominee on and the next
 // candidate is decided in f64 as well, so near-ties are ordered by their f64 depths, not by fp32 keys.
 // The float part (two roots and the median) is packed for the two rays of a lane; the integer part is per ray.
-__device__ __forceinline__ f2 root_keys2(f2 b, f2 disc, float far_slack) {
+__device__ __forceinline__ f2 root_keys2(f2 b, f2 disc) {
     const f2 s = f2{__builtin_amdgcn_sqrtf(disc.x), __builtin_amdgcn_sqrtf(disc.y)};  // NaN for disc < 0
     // A key must be a LOWER bound of the exact depth (hit_end stops looking once the next key exceeds the exact best).
     // The near root b - s is one (the inflated direction and the widened radius both lower it); the far root b + s is
-    // not: the widened radius and the roundings raise disc by up to D = 2.5 W (W: nr2_scan's widening, scan_layout.h),
-    // which raises s = sqrt(disc) by up to sqrt(D) -- far more than the keys' error bound when the ray runs tangent just
-    // inside the surface.  So a ray that starts inside a sphere (near root behind, far root ahead) gets the key
-    // t = max(b + s - far_slack, +0) for it, far_slack = sqrt(4 W) of the largest scan sphere (ScanLists::far_slack):
-    // as SIGNED bit patterns (negative floats are negative ints) the median of (bits(b + s - far_slack), 0, bits(b + s))
-    // is that when the far root is ahead and a negative float's pattern when it is behind; for disc < 0 both are NaNs
-    // of one sign, and the median is that NaN's pattern (above +inf's, or sign bit set).  As UNSIGNED patterns anything
-    // with the sign bit set loses to any non-negative float, so the key is umin(bits(b - s), t): the near root when it is
-    // ahead (or t, a weaker lower bound of it, when the chord is shorter than far_slack), else t, else a pattern that
-    // never wins.  (Round 3 first keyed a far root +0: every ray inside a glass sphere then nominated that sphere first
-    // and was traced again when anything else lay nearer than the way out: 85 % of all unfinished traces.)
-    const f2 k1 = b - s, k2 = b + s;
+    // not -- the widened radius raises it, by far more than the keys' error bound when the ray runs tangent just inside
+    // the surface -- so a ray that starts inside a sphere (near root negative, far root ahead) gets the key +0 for it:
+    // the median of (b - s, b + s, z) with z = disc * 0 (+0, or -0 when disc < 0) is the near root when that is ahead,
+    // +0 when only the far root is, and the (negative: loses as an unsigned pattern) far root when both are behind;
+    // for disc < 0 the two roots are NaNs, v_med3_f32 then returns the minimum of its non-NaN operands: -0, which loses.
+    const f2 k1 = b - s, k2 = b + s, z = disc * splat2(0.0f);
 #ifdef RT_X_OLDKEY
     return f2{__uint_as_float(min(__float_as_uint(k1.x), __float_as_uint(k2.x))), __uint_as_float(min(__float_as_uint(k1.y), __float_as_uint(k2.y)))};
 #else
-    const f2 k2l = k2 - splat2(far_slack);
-    auto med0 = [](float lo, float hi) {  // v_med3_i32(lo, 0, hi)
-        const int a = __float_as_int(lo), c = __float_as_int(hi);
-        return (uint32_t)max(min(a, 0), min(max(a, 0), c));
-    };
-    return f2{__uint_as_float(min(__float_as_uint(k1.x), med0(k2l.x, k2.x))), __uint_as_float(min(__float_as_uint(k1.y), med0(k2l.y, k2.y)))};
+    return f2{__builtin_amdgcn_fmed3f(k1.x, k2.x, z.x), __builtin_amdgcn_fmed3f(k1.y, k2.y, z.y)};
 #endif
 }
 template <bool kFloor>
@@ -444,7 +432,7 @@ __device__ unsigned long long g_dbg[8];  // 0 groups, 1 groups taken, 2 spheres 
 // expanded pre-filter for the static list, the direct ones for the moving list); `direct(k, b, disc)` yields the
 // direct-form b and disc of sphere k for both rays.
 template <bool kFloor, class Direct>
-__device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direct&& direct, float far_slack, int slot0, const Floor& fl,
+__device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direct&& direct, int slot0, const Floor& fl,
                                                uint32_t& best_a, uint32_t& best_b, uint32_t& second_a, uint32_t& second_b,
                                                int& idx_a, int& idx_b, unsigned* dbg) {
 #pragma unroll
@@ -455,7 +443,7 @@ __device__ __forceinline__ void roots_of_group(const f2 (&filter)[kGroup], Direc
             direct(k, b, disc);
             RT_STAT(2, 1);
             RT_STAT(3, __popcll(__builtin_amdgcn_ballot_w64(disc.x >= 0)) + __popcll(__builtin_amdgcn_ballot_w64(disc.y >= 0)));
-            const f2 key = root_keys2(b, disc, far_slack);
+            const f2 key = root_keys2(b, disc);
             take_root<kFloor>(key.x, slot0 + k, fl.lo_a, fl.ls_a, best_a, second_a, idx_a);
             take_root<kFloor>(key.y, slot0 + k, fl.lo_b, fl.ls_b, best_b, second_b, idx_b);
         }
@@ -519,7 +507,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                     f2 q;
                     terms_static_direct(sp[k], nr2[k], r, b, q);
                     d = fma2(b, b, -q);
-                }, S.far_slack, base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
+                }, base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         };
     // HIERARCHICAL CULLING.  Upload stores a bounding sphere around each group of kGroup list neighbours (Morton
@@ -563,7 +551,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
                     f2 q;
                     terms_static_direct(sp[k], nr2[k], r, b, q);
                     d = fma2(b, b, -q);
-                }, S.far_slack, S.ns_pad + base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
+                }, S.ns_pad + base, fl, best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         });
     };
@@ -634,7 +622,7 @@ __device__ __forceinline__ void scan_spheres(const ScanLists& S, const Pair& r, 
             RT_STAT(0, 1);
             if (RT_TAILCOND) {
                 RT_STAT(1, 1);
-                roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.far_slack, S.ns_pad + S.np_pad + base, fl,
+                roots_of_group<kFloor>(disc, [&](int k, f2& bb, f2& d) { bb = b[k]; d = disc[k]; }, S.ns_pad + S.np_pad + base, fl,
                                        best_a, best_b, second_a, second_b, idx_a, idx_b, dbg);
             }
         });

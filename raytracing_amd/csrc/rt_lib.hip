@@ -409,7 +409,6 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                 L.mov_levels = sparse_pass ? K->S.lists.mov_levels_sparse : K->S.lists.mov_levels;
                 L.mov_axes = K->S.lists.mov_axes;
                 L.nm_pad = K->S.lists.nm_pad;
-                L.far_slack = K->S.lists.far_slack;
                 if (kPlanar) {  // (the other variant never reads these)
                     L.plan = K->S.lists.plan;
                     L.plan_nr2 = K->S.lists.plan_nr2;
@@ -934,7 +933,6 @@ int rt_upload_scene(rt_ctx* c, const rt_scene* s) {
     D.lists.ox = lay.org[0]; D.lists.oy = lay.org[1]; D.lists.oz = lay.org[2];
     D.lists.cmax = lay.cmax;
     D.lists.key_eps0 = lay.key_eps0;
-    D.lists.far_slack = lay.far_slack;
     D.lists.stat_levels = lay.stat_levels;
     D.lists.mov_levels = lay.mov_levels;
     D.lists.plan_levels = lay.plan_levels;

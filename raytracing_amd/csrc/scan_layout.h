@@ -93,7 +93,6 @@ struct ScanLayout {
     int32_t stat_levels_sparse = 0, plan_levels_sparse = 0, mov_levels_sparse = 0;
     int32_t mov_axes = 0, any_moving = 0;
     float cmax = 0.0f, key_eps0 = 0.0f;
-    float far_slack = 0.0f;                              // see root_keys2 (rt_device.h): sqrt(4 W) of the largest scan sphere
     double reach = 0.0;
 
     // Validates the spheres (finite, r > 0, material ids) and fills everything above.  RT_OK or an rt_status + text.
@@ -145,7 +144,7 @@ struct ScanLayout {
             any_small = true;
         }
         org[0] = (float)(0.5 * (lo3[0] + hi3[0])); org[1] = (float)(0.5 * (lo3[1] + hi3[1])); org[2] = (float)(0.5 * (lo3[2] + hi3[2]));
-        double cmax = 0.0, reach = 0.0, r_scan_max = 0.0;
+        double cmax = 0.0, reach = 0.0;
         // The planar list (ScanLists::plan): the largest set of static small spheres whose centres share one coordinate
         // EXACTLY (compared in the scan frame, where the kernel multiplies them), when it has at least kPlanarMin members.
         // Below that the separate walk costs more than the cheaper tests save (Random, 97 static spheres in y = 0.2:
@@ -186,7 +185,6 @@ struct ScanLayout {
             const double cx = (double)s->c0x[i] - org[0], cy = (double)s->c0y[i] - org[1], cz = (double)s->c0z[i] - org[2];
             const double ex = cx + s->dcx[i], ey = cy + s->dcy[i], ez = cz + s->dcz[i];
             reach = std::max(reach, std::max(std::sqrt(cx * cx + cy * cy + cz * cz), std::sqrt(ex * ex + ey * ey + ez * ez)) + (double)s->radius[i]);
-            r_scan_max = std::max(r_scan_max, (double)s->radius[i]);
         }
         // -r^2 as the DIRECT form of the scan's test reads it (rt_device.h: terms_static_direct, terms_moving), widened so
         // that the test stays conservative where the direction's inflation (kScanInflate, 16 ulp of b^2) cannot help: a
@@ -359,10 +357,6 @@ struct ScanLayout {
         this->cmax = (float)(cmax * (1.0 + 1e-6));
         this->reach = reach;
         key_eps0 = (float)(reach * (1.0 + 1e-6)) * kKeyEps0;
-        // disc as the scan computes it exceeds the exact one by at most W (the widening) + W / 2 (the roundings it covers
-        // twice over) + 16 ulp of b^2 <= r^2 (the inflated direction, for an origin inside the sphere): < 2.5 W.  4 W, of
-        // the largest radius (W grows with r), rounded up: s = sqrt(disc) is then at most far_slack too large.
-        far_slack = (float)(std::sqrt(4.0 * kDirectSlack * (r_scan_max * r_scan_max + r_scan_max * reach)) * (1.0 + 1e-3));
         mov_axes = 0;
         for (const F4& v : mov_b) mov_axes |= (v.x != 0.0f ? 1 : 0) | (v.y != 0.0f ? 2 : 0) | (v.z != 0.0f ? 4 : 0);
         // a wave with few live rays (the end of a launch) meets few nodes: every level with at least two nodes is worth its tests

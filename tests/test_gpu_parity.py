@@ -870,6 +870,28 @@ def test_scaled_scenes(ctx, api, orc, name, k):
     assert r < 8e-4 and abs(int(st1.rays_traced) - int(st0.rays_traced)) < 5e-4 * st0.rays_traced  # measured 9e-5 .. 2.4e-4 (64 spp), rays <= 1.2e-4
 
 
+def test_near_root_just_ahead_of_the_scan_start(ctx, api, orc):
+    """tools/fuzz_parity.py case 31702 (tests/golden/make_near_root_case.py): 3000 overlapping spheres; the last ray starts
+    INSIDE one sphere and 4e-5 radii outside another whose near root (t = 0.0010676) is 7e-5 above t_min = 0.001.  The
+    widened scan-side radius puts that near root behind the scan's start in fp32, so the sphere looks like one the ray
+    starts inside: such a candidate must be keyed +0 (a lower bound whichever it is).  A round-3 build that keyed it by
+    its far root (0.43) let the next sphere (0.0038) win.  ids bit-exact, nothing excluded."""
+    g = golden("near_root_just_ahead.npz")
+    n_s = len(g["radius"])
+    mats = [(api.RT_MAT_LAMBERTIAN, (0.5, 0.5, 0.5), 0, 0, 0)]
+    fs = api.FlatScene(g["c0"], g["radius"], np.zeros(n_s, np.uint32), mats, [api.solid_texture((0.5, 0.5, 0.5))])
+    ctx.upload(fs.scene)
+    assert ctx.debug_scan_layout()["planar_slots"] == 1920
+    rays = np.zeros(len(g["time"]), api.ray_dtype)
+    rays["origin"], rays["dir"], rays["time"] = g["origin"], g["dir"], g["time"]
+    t_min = float(g["t_min"])
+    got = ctx.intersect_batch(rays, t_min)
+    exp = orc.intersect_batch(fs.scene, rays, t_min)
+    assert exp["sphere_id"][-1] == 1473 and abs(float(exp["t"][-1]) - 0.0010675772) < 1e-9
+    st = check_hits(got, exp, EPS_MARGIN, TOL, max_excluded=0.0)
+    print(st)
+
+
 def test_small_spheres_far_from_the_rays(ctx, api, orc):
     """|oc| / r in the thousands: radius-0.1 spheres seen from 300-600 away.  A plain fp32 discriminant b^2 - (|oc|^2
     - r^2) has an ulp of |oc|^2 (0.008 at 300) against r^2 = 0.01, i.e. hits or misses such spheres at random; the

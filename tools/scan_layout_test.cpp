@@ -181,12 +181,6 @@ static void check_layout(const char* name, Scene& sc, const LayoutOptions& opt =
     check_list("planar", sc, L, L.plan, nullptr, &L.plan_nr2, L.plan_id, L.plan_bound, L.plan_levels, L.plan_levels_sparse);
     check_list("moving", sc, L, L.mov_a, &L.mov_b, nullptr, L.mov_id, L.mov_bound, L.mov_levels, L.mov_levels_sparse);
     CHECK(L.key_eps0 >= (float)L.reach * kKeyEps0 && L.key_eps0 <= (float)L.reach * kKeyEps0 * 1.0001f, "%s key_eps0", name);
-    {  // far_slack (root_keys2): at least sqrt(2.5 W) of every scan sphere, W = the widening of its scan-side r^2
-        double w_max = 0.0;
-        for (size_t i = 0; i < n; ++i)
-            if (!L.is_big[i]) w_max = std::max(w_max, kDirectSlack * ((double)sc.rad[i] * sc.rad[i] + (double)sc.rad[i] * L.reach));
-        CHECK((double)L.far_slack >= std::sqrt(2.5 * w_max) && (double)L.far_slack <= std::sqrt(4.0 * w_max) * 1.01 + 1e-30, "%s far_slack %g vs W %g", name, (double)L.far_slack, w_max);
-    }
     int axes = 0, moving = 0;
     for (size_t i = 0; i < n; ++i) {
         const bool mv = sc.dcx[i] != 0 || sc.dcy[i] != 0 || sc.dcz[i] != 0;
