@@ -891,7 +891,11 @@ struct Hit2 {
 // the scan with or without the floor, chosen per wave
 template <bool kPlanar>
 __device__ __forceinline__ void scan_with_floor(const ScanLists& L, const Floor& fl, Hit2& x) {
+#ifdef RT_X_ALWAYSFLOOR  // what a pass with a retracing lane costs: every pass takes the floor variant
+    if (true)
+#else
     if (__ballot(fl.lo_a >= 0 || fl.lo_b >= 0) != 0ull)
+#endif
         scan_spheres<true, kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.second_a, x.second_b, x.slot_a, x.slot_b);
     else
         scan_spheres<false, kPlanar>(L, x.p, fl, x.best_a, x.best_b, x.second_a, x.second_b, x.slot_a, x.slot_b);

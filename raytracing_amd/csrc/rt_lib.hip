@@ -386,7 +386,11 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             const bool retry_a = ps[0].alive && h[0].sphere == kRetry, retry_b = ps[1].alive && h[1].sphere == kRetry;
             const Floor fl = {retry_a ? retry_key(h[0]) : -1, retry_b ? retry_key(h[1]) : -1,
                               retry_slot(h[0]), retry_slot(h[1])};
+#ifdef RT_X_ALWAYSFLOOR
+            const bool any_retry = true;
+#else
             const bool any_retry = __ballot(retry_a || retry_b) != 0ull;  // wave-uniform: most passes have none
+#endif
             RT_MARK("begin");
             {
                 const ArgsPtr K = launder(K0);
