@@ -175,8 +175,8 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
 
     for (;;) {
         // The unit-queue state is wave-uniform, but the compiler keeps these loop-carried values in VGPRs (nine of them,
-        // live across the whole pass) unless each is re-declared uniform once per pass: with them in SGPRs no variant of
-        // the kernel spills a VGPR (with them in VGPRs: 5 to 33 spilled, scratch round trips in the scan's cold side).
+        // live across the whole pass) unless each is re-declared uniform once per pass: with them in SGPRs no variant that
+        // a BASELINE scene runs spills a VGPR (with them in VGPRs: 5 to 33 spilled, scratch round trips in the scan's cold side).
         next = __builtin_amdgcn_readfirstlane(next); total = __builtin_amdgcn_readfirstlane(total);
         tx0 = __builtin_amdgcn_readfirstlane(tx0); ty0 = __builtin_amdgcn_readfirstlane(ty0);
         tw = __builtin_amdgcn_readfirstlane(tw); npix = __builtin_amdgcn_readfirstlane(npix);

@@ -3,6 +3,8 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import torch
 from raytracing_amd import api
+if os.environ.get('RTX_HIP_LIB'):
+    api.allow_lib_override()  # A/B tooling (tools/spp_sweep_libs.sh)
 ctx = api.Context(0)
 w = api.World("FinalStatic", seed=1, aspect=1.5)
 ctx.upload(w.scene)
