@@ -30,6 +30,18 @@ int rt_debug_set_planar_list(rt_ctx* ctx, int on);
  * rounding of the hit record's inputs (both decide hits in f64). */
 int rt_debug_set_direct(rt_ctx* ctx, int on);
 
+/* Effective only in experiment builds (-DRT_X_TAILORDER, rt_lib.hip: build_tail_order), no-ops otherwise.
+ * on = 0: renders deal the small work units at the end of a launch in tile-index order, as the product build does,
+ * instead of dealing the tiles that bred long paths (32 segments or more) earlier in the launch first, most of them
+ * first; on != 0 restores the experiment's order.  Scheduling only: results are identical bit for bit. */
+int rt_debug_set_tail_order(rt_ctx* ctx, int on);
+
+/* After a render through an allocating entry point: out = {1 if the last launch built a tail order else 0, the number of
+ * tiles on which a long path had been counted by then (they are dealt before the others, most counts first), 1 if the
+ * order read back from the device is a permutation of the tiles with ascending class starts (checked on the host)}.
+ * All zeros in the product build. */
+int rt_debug_tail_order_stats(rt_ctx* ctx, uint32_t out[3]);
+
 /* n = 1 or 2: the next rt_upload_scene gives every wave that many tile buffers in LDS (2: the in-flight paths of a
  * finished work unit keep adding into their tile's LDS sums; 1: they add straight into the global accumulators) when
  * that many fit; 0 restores the choice by LDS room and occupancy.  Results are identical. */

@@ -117,7 +117,7 @@ ABI_SYMBOLS = [
     "rth_world_render_seed", "rth_world_bvh_first", "rth_last_error", "rth_scene_names", "rth_camera_build",
     # include/rtx_hip_debug.h (test / tuning hooks, not part of the drop-in ABI)
     "rt_debug_set_work_units", "rt_debug_set_scan_order", "rt_debug_set_tile_buffers", "rt_debug_set_planar_list",
-    "rt_debug_scan_layout", "rt_debug_set_direct", "rt_debug_multi",
+    "rt_debug_scan_layout", "rt_debug_set_direct", "rt_debug_multi", "rt_debug_set_tail_order", "rt_debug_tail_order_stats",
 ]
 
 _lib = None
@@ -191,6 +191,9 @@ def load() -> C.CDLL:
         lib.rt_debug_multi.argtypes = [C.c_int]
     if hasattr(lib, "rt_debug_set_direct"):
         lib.rt_debug_set_direct.argtypes = [vp, C.c_int]
+    if hasattr(lib, "rt_debug_set_tail_order"):
+        lib.rt_debug_set_tail_order.argtypes = [vp, C.c_int]
+        lib.rt_debug_tail_order_stats.argtypes = [vp, C.POINTER(C.c_uint32 * 3)]
     if hasattr(lib, "rt_debug_set_planar_list"):  # (absent from older builds that tools/ab*.sh compare against)
         lib.rt_debug_set_planar_list.argtypes = [vp, C.c_int]
         lib.rt_debug_scan_layout.argtypes = [vp, C.POINTER(C.c_int32 * 8)]
@@ -455,6 +458,17 @@ class Context:
         """include/rtx_hip_debug.h: static spheres with a shared centre coordinate in their own scan list (default) or
         in the general one, from the next upload on."""
         self._check(self.lib.rt_debug_set_planar_list(self._h, 1 if on else 0))
+
+    def debug_set_tail_order(self, on: bool = True):
+        """include/rtx_hip_debug.h: the small units at the end of a launch dealt long-path tiles first (default) or in
+        tile-index order."""
+        self._check(self.lib.rt_debug_set_tail_order(self._h, 1 if on else 0))
+
+    def debug_tail_order_stats(self) -> dict:
+        """include/rtx_hip_debug.h: whether the last launch built a tail order and how many tiles it dealt first."""
+        out = (C.c_uint32 * 3)()
+        self._check(self.lib.rt_debug_tail_order_stats(self._h, C.byref(out)))
+        return {"built": int(out[0]), "marked_tiles": int(out[1]), "valid": int(out[2])}
 
     def debug_set_direct(self, on: bool = True):
         """include/rtx_hip_debug.h: scenes of a handful of spheres entirely on the f64 list and rendered by the kernel

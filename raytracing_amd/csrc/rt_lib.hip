@@ -30,12 +30,23 @@ constexpr int kTile = 8;             // a wave owns an 8x8 pixel tile
 // 1/8 of the) samples of a launch, which are cut into kUnitSppB-sample units so that the waves finish together.
 constexpr uint32_t kUnitSppA = 48, kUnitSppB = 8, kTailSpan = 128;
 constexpr uint32_t kMaxBatch = 1u << 30;  // elements per batch call (grid sizes are computed in 32 bits)
+// EXPERIMENT (-DRT_X_TAILORDER; DESIGN.md 7, tools/tail_order_ab.py): measured -1.7 % on configs[2] and -1 % on 500-spp
+// renders of configs[1]'s scene, but +-0 on configs[1] itself, +0.5 % on the 4K share and +1.5 % on the two-sphere noise
+// scenes, so the product build leaves it out (the code of build_tail_order and its users is dead then: kTailOrderOn folds it away).
+#ifdef RT_X_TAILORDER
+constexpr bool kTailOrderOn = true;
+#else
+constexpr bool kTailOrderOn = false;
+#endif
 // Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
 // radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
 // per GPU, held until the process ends (24 MiB + 256 B).  In host code this NAME is only a handle for
 // hipGetSymbolAddress (rt_create); everything else uses the per-device address kept in rt_ctx::scratch.
 constexpr size_t kScratchAccum = (size_t)RT_NOALLOC_MAX_PIXELS * 3;  // u64 elements
-constexpr size_t kScratchWords = kScratchAccum + 32;                 // + [0] ray counter, [1] unit counter (+ pad)
+// then [0] ray counter, [1] unit counter (+ pad to 32 words), then the tail order of the launch (build_tail_order:
+// 16 + 3 * tiles u32; an image of RT_NOALLOC_MAX_PIXELS pixels has at most that many / 16 tiles of 8x8: width >= 2)
+constexpr size_t kScratchOrderTiles = kTailOrderOn ? (size_t)RT_NOALLOC_MAX_PIXELS / 16 : 0;  // (experiment builds only)
+constexpr size_t kScratchWords = kScratchAccum + 32 + (kTailOrderOn ? (16 + 3 * kScratchOrderTiles) / 2 : 0);
 static __device__ __align__(256) unsigned long long g_noalloc_scratch[kScratchWords];
 
 struct RenderArgs {
@@ -56,6 +67,7 @@ struct RenderArgs {
     unsigned long long* accum;  // W*H*3 fixed-point (2^-32) radiance sums
     unsigned long long* rays;
     unsigned int* unit_counter;  // next unclaimed work unit (zeroed before the launch)
+    uint32_t* order;             // tile order of the launch's tail (see build_tail_order); NULL: tiles in index order
 };
 
 // PERSISTENT waves over a queue of work units.  The grid is exactly the waves the GPU holds at once; a unit is
@@ -71,6 +83,70 @@ struct RenderArgs {
 // bit-reproducible images whatever the chunking, tiling or scheduling): LDS per wave and tile, then one global
 // atomic per pixel-channel when the tile's buffer is retired.  (With one buffer the in-flight paths of every
 // finished unit, ~all 128 slots, were orphans: two thirds of the kernel's HBM traffic.)
+// LONG PATHS FIRST in the tail of a launch.  A path of max_depth segments is that many SERIAL passes (5 ms at 100
+// bounces in a busy wave); one that starts in the last round of units keeps its wave -- and the launch -- going long after
+// the other 3071 waves have left (measured: the mean wave exits 0.3 ms after the queue empties, the last one 3.7 ms).
+// Which pixels breed such paths is stable (glass: total internal reflection), so the launch learns it: a path that
+// reaches kLongDepth segments is counted on its TILE, and when the queue reaches the small units of the tail
+// (RenderArgs::n_a on) the tiles are dealt by class of that count, highest first (kOrderClasses classes: 256 and
+// more, 64.., 16.., 8.., 4.., 2.., 1, none): all tail units of a class, chunk-major as before, then the next class.
+// The tiles that breed long paths all the time then start theirs while most of the tail's work is still to come, and
+// the last rounds of units hold tiles that have bred none in the whole launch so far.  Any order of the units gives the
+// same image (order-free sums, counter RNG), so this is scheduling only.
+// Workspace `order` (u32): [0] ready flag of this launch's order, [1 .. 1 + kOrderClasses] where each class starts in the
+// order (the last entry = n_tiles), [16, 16 + n_tiles) the counts (kept over the launches of a render), then n_tiles
+// entries: the tiles in the order they are dealt, then n_tiles entries of builder scratch.  The wave that claims unit tail_order_trigger() -- halfway
+// through the big units, long before the tail: one wave's two passes over the counts take ~1 ms for 15 000 tiles and ~8 ms
+// for a 4K image -- builds the order; a wave that claims a tail unit before it is ready waits for it -- the builder is resident and running, so the
+// wait is finite.  A launch without big units (128 spp or fewer) has nothing to learn from and keeps the index order
+// (the host passes no workspace).
+constexpr uint32_t kLongDepth = 32;
+constexpr int kOrderClasses = 8;
+constexpr uint32_t kOrderHeader = 16;
+__host__ __device__ inline uint32_t tail_order_trigger(uint32_t n_big, uint32_t) { return n_big / 2u; }
+__device__ __forceinline__ int order_class(uint32_t count) {  // 0 = dealt first
+    return count >= 256u ? 0 : count >= 64u ? 1 : count >= 16u ? 2 : count >= 8u ? 3 : count >= 4u ? 4 : count >= 2u ? 5 : count >= 1u ? 6 : 7;
+}
+__device__ __attribute__((noinline)) void build_tail_order(uint32_t* order, uint32_t n_tiles, int lane) {
+    const uint32_t* __restrict__ counts = order + kOrderHeader;
+    uint32_t* __restrict__ perm = order + kOrderHeader + n_tiles;
+    uint32_t* __restrict__ snap = order + kOrderHeader + 2 * n_tiles;  // each tile's class as the first pass saw it: the counts go on growing
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);  // (the counts are device-scope atomics; do not read them from a stale line)
+    uint32_t start[kOrderClasses + 1];
+#pragma unroll
+    for (int k = 0; k <= kOrderClasses; ++k) start[k] = 0;
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 64) {  // class sizes (plain loads behind the fence: they pipeline)
+        const uint32_t t = t0 + (uint32_t)lane;
+        const int cls = t < n_tiles ? order_class(counts[t]) : -1;
+        if (t < n_tiles) snap[t] = (uint32_t)cls;
+#pragma unroll
+        for (int k = 0; k < kOrderClasses; ++k) start[k + 1] += (uint32_t)__popcll(__ballot(cls == k));
+    }
+#pragma unroll
+    for (int k = 0; k < kOrderClasses; ++k) start[k + 1] += start[k];  // start[k] = first entry of class k; start[last] = n_tiles
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t pos[kOrderClasses];
+#pragma unroll
+    for (int k = 0; k < kOrderClasses; ++k) pos[k] = start[k];
+    for (uint32_t t0 = 0; t0 < n_tiles; t0 += 64) {
+        const uint32_t t = t0 + (uint32_t)lane;
+        const int cls = t < n_tiles ? (int)snap[t] : -1;  // (this lane's own store of the first pass)
+#pragma unroll
+        for (int k = 0; k < kOrderClasses; ++k) {
+            const unsigned long long bk = __ballot(cls == k);
+            if (cls == k) perm[pos[k] + (uint32_t)__popcll(bk & lt)] = t;
+            pos[k] += (uint32_t)__popcll(bk);
+        }
+    }
+    if (lane <= kOrderClasses) {
+        uint32_t v = 0;
+#pragma unroll
+        for (int k = 0; k <= kOrderClasses; ++k) v = lane == k ? start[k] : v;
+        order[1 + lane] = v;
+    }
+    __atomic_thread_fence(__ATOMIC_RELEASE);  // every lane's entries before lane 0's flag
+    if (lane == 0) __hip_atomic_store(order, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
 struct PathState {
     Ray ray;
     f3 thr;
@@ -107,6 +183,9 @@ __host__ __device__ inline size_t block_lds_bytes(size_t scene_bytes, uint32_t a
 template <bool kNoise, bool kTwoBufs, int kScan>
 __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const RenderArgs A_kernarg) {
     constexpr bool kPlanar = kScan == 1, kDirect = kScan == 2;
+    // (the variants with noise textures AND scan lists have no registers to spare for it -- 20 to 30 VGPRs spilled -- and no
+    // BASELINE scene runs them: they keep the index order)
+    constexpr bool kTailOrder = kTailOrderOn && (!kNoise || kDirect);
     // Arguments used in ONE place per pass are not kept in SGPRs across the whole loop (the allocator could only do
     // that by spilling them to VGPR lanes: v_readlane/v_writelane are VALU slots).  The camera and image geometry
     // (refill) and the scan-list fields (scan) are re-read from the kernarg segment (constant address space =>
@@ -199,10 +278,47 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
             const ArgsPtr K = launder(K0);  // the launch plan: read here (once per ~65 passes), not held in SGPRs
             uint32_t u = 0;
             if (lane == 0) u = atomicAdd(K->unit_counter, 1u);
+            // The header of the tail order (lane 0: its ready flag, lanes 1 .. kOrderClasses + 1: where each class starts) is
+            // fetched alongside the counter, not after it: a claim costs one memory round trip, as before.  Device-scope
+            // atomic loads: they bypass the non-coherent cache levels; one instruction, one line: a set flag comes with the
+            // starts written before it.
+            uint32_t* const order = kTailOrder ? K->order : nullptr;
+            uint32_t hdr = 0;
+            if (order != nullptr && lane <= kOrderClasses + 1) hdr = __hip_atomic_load(order + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             u = __builtin_amdgcn_readfirstlane(u);
             next = 0;
             if (u < K->n_units) {
-                const uint32_t tile = u % K->n_tiles, chunk = u / K->n_tiles;
+                uint32_t tile = u % K->n_tiles, chunk = u / K->n_tiles;
+                const uint32_t n_big = K->n_a * K->n_tiles;
+                if (order != nullptr && u == tail_order_trigger(n_big, K->n_tiles)) build_tail_order(order, K->n_tiles, lane);
+                if (order != nullptr && u >= n_big) {  // a tail unit: tiles in the launch's learned order (build_tail_order)
+                    const uint32_t n_tiles = K->n_tiles;
+                    if (__builtin_amdgcn_readfirstlane(hdr) == 0u) {  // not built yet (rare: the build starts half a launch earlier): wait
+                        do {
+                            __builtin_amdgcn_s_sleep(16);
+                            if (lane <= kOrderClasses + 1) hdr = __hip_atomic_load(order + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        } while (__builtin_amdgcn_readfirstlane(hdr) == 0u);
+                        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+                        if (lane <= kOrderClasses + 1) hdr = __hip_atomic_load(order + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    const uint32_t w = u - n_big, tail_chunks = K->n_units / n_tiles - K->n_a;
+                    const uint32_t n_counted = (uint32_t)__builtin_amdgcn_readlane((int)hdr, kOrderClasses);  // tiles outside the last class
+                    if (n_counted != 0u) {  // (no long path anywhere so far: the order is the index order, nothing to look up)
+                        uint32_t idx = 0;
+#pragma unroll
+                        for (int k = 0; k < kOrderClasses; ++k) {  // the class whose units hold w: units [start * tail_chunks, next * tail_chunks)
+                            const uint32_t s0 = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 1 + k), s1 = (uint32_t)__builtin_amdgcn_readlane((int)hdr, 2 + k);
+                            if (w >= s0 * tail_chunks && w < s1 * tail_chunks) {
+                                const uint32_t v = w - s0 * tail_chunks, n_k = s1 - s0;
+                                idx = s0 + v % n_k;
+                                chunk = K->n_a + v / n_k;
+                            }
+                        }
+                        uint32_t tl = 0;
+                        if (lane == 0) tl = __hip_atomic_load(order + kOrderHeader + n_tiles + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        tile = min((uint32_t)__builtin_amdgcn_readfirstlane(tl), n_tiles - 1u);  // (an entry is always a tile index; never index the image with anything else)
+                    }
+                }
                 tx0 = (tile % K->tiles_x) * kTile;
                 ty0 = (tile / K->tiles_x) * kTile;
                 tw = min((uint32_t)kTile, K->W - tx0);
@@ -465,6 +581,9 @@ __global__ __launch_bounds__(kBlock, RT_WAVES_PER_EU) void render_kernel(const R
                     }
                 } else if (P.depth + 1 == K->max_depth) {
                     P.alive = false;
+                } else if (kTailOrder && P.depth + 1 == kLongDepth && K->order != nullptr) {  // a long path: count it on its tile (build_tail_order)
+                    const uint32_t py = P.pix / K->W, px = P.pix - py * K->W;
+                    atomicAdd(K->order + kOrderHeader + (py / kTile) * K->tiles_x + px / kTile, 1u);
                 }
             }
         }
@@ -649,6 +768,10 @@ struct rt_ctx {
     // render workspace
     unsigned long long* accum = nullptr;
     size_t accum_cap = 0;  // elements
+    uint32_t* order = nullptr;  // tail order workspace of the allocating entry points (build_tail_order)
+    size_t order_cap = 0;       // tiles
+    uint32_t order_tiles = 0;   // tiles of the last render that used `order` (rt_debug_tail_order_stats)
+    bool dbg_no_tail_order = false;
     unsigned long long* rays = nullptr;
     float* out = nullptr;
     size_t out_cap = 0;
@@ -782,6 +905,7 @@ void rt_destroy(rt_ctx* c) {
     (void)hipSetDevice(c->device);
     free_scene(c);
     if (c->accum) (void)hipFree(c->accum);
+    if (c->order) (void)hipFree(c->order);
     if (c->rays) (void)hipFree(c->rays);
     if (c->out) (void)hipFree(c->out);
     if (c->pinned_rays) (void)hipHostFree(c->pinned_rays);
@@ -999,10 +1123,14 @@ static int check_render_args(rt_ctx* c, const rt_camera* cam, const rt_params* p
 // this device's static scratch array.  Allocates nothing.  sync = false leaves the work in flight (multi-device
 // callers launch on every device first); render_finish waits and fills the stats.
 static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, unsigned long long* accum,
-                         unsigned long long* counters, float* d_out, double out_scale, uint32_t* n_launches) {
+                         unsigned long long* counters, uint32_t* order, float* d_out, double out_scale, uint32_t* n_launches) {
     const size_t n_px = (size_t)p->width * p->height, n_el = n_px * 3;
+    if (!kTailOrderOn || c->dbg_no_tail_order) order = nullptr;  // (an experiment: -DRT_X_TAILORDER) rt_debug_set_tail_order
     RT_HIP(c, hipEventRecord(c->ev0, c->stream));
     RT_HIP(c, hipMemsetAsync(accum, 0, n_el * sizeof(unsigned long long), c->stream));
+    if (order == c->order) c->order_tiles = order ? ((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile) : 0;
+    if (order)  // ready flag, class starts and the tiles' counts (kept over the launches of this render)
+        RT_HIP(c, hipMemsetAsync(order, 0, (kOrderHeader + (size_t)((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile)) * sizeof(uint32_t), c->stream));
     RT_HIP(c, hipMemsetAsync(counters, 0, sizeof(unsigned long long), c->stream));
 
     RenderArgs A{};
@@ -1056,6 +1184,8 @@ static int render_launch(rt_ctx* c, const rt_camera* cam, const rt_params* p, un
         A.n_units = (uint32_t)n_units;
         A.unit_counter = reinterpret_cast<unsigned int*>(counters + 1);
         RT_HIP(c, hipMemsetAsync(counters + 1, 0, sizeof(unsigned long long), c->stream));
+        A.order = A.n_a > 0 ? order : nullptr;  // (no big units: nothing to learn the order from)
+        if (order && launches > 0) RT_HIP(c, hipMemsetAsync(order, 0, sizeof(uint32_t), c->stream));  // this launch builds its own order
         const uint32_t blocks = (uint32_t)std::min<uint64_t>(resident_blocks, (n_units + kWavesPerBlock - 1) / kWavesPerBlock);
         hipLaunchKernelGGL(render_variant(noise, c->acc_bufs == 2, c->scan_mode), dim3(blocks), dim3(kBlock), lds_bytes, c->stream, A);
         RT_HIP(c, hipGetLastError());
@@ -1095,6 +1225,16 @@ static int ensure_accum(rt_ctx* c, size_t n_el) {
     c->accum_cap = n_el;
     return RT_OK;
 }
+static uint32_t tiles_of(const rt_params* p) { return ((p->width + kTile - 1) / kTile) * ((p->height + kTile - 1) / kTile); }
+static int ensure_order(rt_ctx* c, size_t n_tiles) {
+    if (!kTailOrderOn || c->order_cap >= n_tiles) return RT_OK;
+    if (c->order) (void)hipFree(c->order);
+    c->order = nullptr; c->order_cap = 0;
+    if (hipMalloc((void**)&c->order, (kOrderHeader + 3 * n_tiles) * sizeof(uint32_t)) != hipSuccess)
+        return fail(c, RT_ERR_ALLOC, "cannot allocate the tile order of the launch tail");
+    c->order_cap = n_tiles;
+    return RT_OK;
+}
 
 static const double kFixedToFloat = 1.0 / 4294967296.0;
 
@@ -1102,8 +1242,9 @@ int rt_render_accum_device(rt_ctx* c, const rt_camera* cam, const rt_params* p, 
     int rc = check_render_args(c, cam, p, d_sum_rgb);
     if (rc != RT_OK) return rc;
     if ((rc = ensure_accum(c, (size_t)p->width * p->height * 3)) != RT_OK) return rc;
+    if ((rc = ensure_order(c, tiles_of(p))) != RT_OK) return rc;
     uint32_t launches = 0;
-    if ((rc = render_launch(c, cam, p, c->accum, c->rays, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK) return rc;
+    if ((rc = render_launch(c, cam, p, c->accum, c->rays, c->order, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK) return rc;
     return render_finish(c, p, launches, stats);
 }
 
@@ -1118,7 +1259,8 @@ int rt_render_accum_device_noalloc(rt_ctx* c, const rt_camera* cam, const rt_par
     uint32_t launches = 0;
     // every call on this GPU shares the array and it keeps the last call's contents: render_launch clears the
     // W*H*3 accumulators it uses and both counters before the kernel reads them
-    if ((rc = render_launch(c, cam, p, c->scratch, c->scratch + kScratchAccum, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK)
+    uint32_t* const order = tiles_of(p) <= kScratchOrderTiles ? reinterpret_cast<uint32_t*>(c->scratch + kScratchAccum + 32) : nullptr;
+    if ((rc = render_launch(c, cam, p, c->scratch, c->scratch + kScratchAccum, order, d_sum_rgb, kFixedToFloat, &launches)) != RT_OK)
         return rc;
     return render_finish(c, p, launches, stats);
 }
@@ -1128,6 +1270,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rg
     if (rc != RT_OK) return rc;
     const size_t n_el = (size_t)p->width * p->height * 3;
     if ((rc = ensure_accum(c, n_el)) != RT_OK) return rc;
+    if ((rc = ensure_order(c, tiles_of(p))) != RT_OK) return rc;
     if (c->out_cap < n_el) {
         if (c->out) (void)hipFree(c->out);
         c->out = nullptr; c->out_cap = 0;
@@ -1136,7 +1279,7 @@ int rt_render(rt_ctx* c, const rt_camera* cam, const rt_params* p, float* out_rg
         c->out_cap = n_el;
     }
     uint32_t launches = 0;
-    if ((rc = render_launch(c, cam, p, c->accum, c->rays, c->out, kFixedToFloat / (double)p->spp, &launches)) != RT_OK) return rc;
+    if ((rc = render_launch(c, cam, p, c->accum, c->rays, c->order, c->out, kFixedToFloat / (double)p->spp, &launches)) != RT_OK) return rc;
     if ((rc = render_finish(c, p, launches, stats)) != RT_OK) return rc;
     RT_HIP(c, hipMemcpy(out_rgb, c->out, n_el * sizeof(float), hipMemcpyDeviceToHost));
     return RT_OK;
@@ -1160,6 +1303,34 @@ int rt_debug_scan_layout(rt_ctx* c, int32_t out[8]) {
     const int32_t v[8] = {c->S.n_big, L.ns_pad, L.np_pad, L.nm_pad, L.np_pad > 0 ? L.plan_axis : -1,
                           L.nm_pad > 0 ? L.mov_axes : 0, (int32_t)c->acc_bufs, c->has_noise ? 1 : 0};
     for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return RT_OK;
+}
+int rt_debug_set_tail_order(rt_ctx* c, int on) {
+    if (!c) return RT_ERR_BAD_ARG;
+    c->dbg_no_tail_order = on == 0;
+    return RT_OK;
+}
+int rt_debug_tail_order_stats(rt_ctx* c, uint32_t out[3]) {
+    if (!c || !out) return RT_ERR_BAD_ARG;
+    out[0] = out[1] = out[2] = 0;
+    if (!c->order || c->order_tiles == 0) return RT_OK;
+    RT_HIP(c, hipSetDevice(c->device));
+    const uint32_t n = c->order_tiles;
+    std::vector<uint32_t> h(kOrderHeader + 2 * (size_t)n);
+    RT_HIP(c, hipMemcpy(h.data(), c->order, h.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+    out[0] = h[0];
+    out[1] = h[kOrderClasses];  // where the last class (no long path seen) starts = the tiles that have bred one
+    if (h[0]) {  // the order must be a permutation of the tiles, and the class starts ascending up to n
+        std::vector<char> seen(n, 0);
+        bool ok = h[1] == 0 && h[1 + kOrderClasses] == n;
+        for (int k = 0; k < kOrderClasses; ++k) ok = ok && h[1 + k] <= h[2 + k];
+        for (uint32_t i = 0; i < n && ok; ++i) {
+            const uint32_t t = h[kOrderHeader + n + i];
+            ok = t < n && !seen[t];
+            if (ok) seen[t] = 1;
+        }
+        out[2] = ok ? 1u : 0u;
+    }
     return RT_OK;
 }
 int rt_debug_set_direct(rt_ctx* c, int on) {
@@ -1483,7 +1654,8 @@ int rt_multi_render(rt_multi* m, const rt_camera* cam, const rt_params* p, float
         }
         // (several entries of one device -- the debug hook -- share that device's GPU but not their workspaces)
         if ((rc = ensure_accum(c, n_el)) != RT_OK) return fail_from(c, rc);
-        if ((rc = render_launch(c, cam, &share[i], c->accum, c->rays, m->dsum[i], kFixedToFloat, &launches[i])) != RT_OK)
+        if ((rc = ensure_order(c, tiles_of(&share[i]))) != RT_OK) return fail_from(c, rc);
+        if ((rc = render_launch(c, cam, &share[i], c->accum, c->rays, c->order, m->dsum[i], kFixedToFloat, &launches[i])) != RT_OK)
             return fail_from(c, rc);
     }
     rt_multi_stats st;
