@@ -40,7 +40,7 @@ constexpr bool kTailOrderOn = false;
 #endif
 // Workspace of rt_render_accum_device_noalloc (the entry point for callers that cannot allocate): the fixed-point
 // radiance accumulators of an image of at most RT_NOALLOC_MAX_PIXELS pixels, then the two launch counters.  One copy
-// per GPU, held until the process ends (24 MiB + 256 B).  In host code this NAME is only a handle for
+// per GPU, held until the process ends (24 MiB + 256 B; + 0.8 MiB in -DRT_X_TAILORDER builds).  In host code this NAME is only a handle for
 // hipGetSymbolAddress (rt_create); everything else uses the per-device address kept in rt_ctx::scratch.
 constexpr size_t kScratchAccum = (size_t)RT_NOALLOC_MAX_PIXELS * 3;  // u64 elements
 // then [0] ray counter, [1] unit counter (+ pad to 32 words), then the tail order of the launch (build_tail_order:
